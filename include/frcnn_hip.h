@@ -1,0 +1,150 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so: the MI355X (gfx950) proposal/RoI hot path of
+ * FurkanOM/tf-faster-rcnn, hand-written HIP.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - tensors are contiguous, row-major, fp32 / int32 / uint8 as declared;
+ *   - boxes are [y1, x1, y2, x2], feature maps NHWC (the reference's layouts);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every entry point
+ *     only enqueues work on that stream: no allocation, no synchronisation;
+ *   - scratch memory comes from the caller: `*_workspace_bytes()` says how much, the pointer
+ *     must be 256-byte aligned;
+ *   - return value: 0 = ok, FRCNN_EINVAL / FRCNN_EUNSUPPORTED / FRCNN_EHIP otherwise, with a
+ *     thread-local message available from frcnn_last_error().  No exception crosses the ABI.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).  The reference has no FFI: its boundary is the Python
+ * functions/Keras layers cited, which delegate to TensorFlow 2.0 ops.
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK 0
+#define FRCNN_EINVAL (-1)       /* bad shape / argument (TF: InvalidArgumentError) */
+#define FRCNN_EUNSUPPORTED (-2) /* size beyond what the kernels are built for */
+#define FRCNN_EHIP (-3)         /* HIP runtime error */
+
+typedef void *frcnn_stream_t;
+
+/* Library version (major*10000 + minor*100 + patch). */
+int frcnn_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char *frcnn_last_error(void);
+
+/* ---- anchors ------------------------------------------------------------------------- */
+/* utils/bbox_utils.py:37-57 generate_anchors: broadcast add of the base anchors (A,4)
+ * (utils/bbox_utils.py:13-34, computed by the host in fp64/fp32 as the reference does) over the
+ * G x G cell centres `grid_coords` (G) and clip to [0,1].  out: (G*G*A, 4). */
+int frcnn_generate_anchors(const float *base_anchors, int A, const float *grid_coords, int G,
+                           float *out, frcnn_stream_t stream);
+
+/* ---- box codec ----------------------------------------------------------------------- */
+/* utils/bbox_utils.py:86-108 get_bboxes_from_deltas.  anchors: (N,4) shared by every batch row
+ * when anchors_batched == 0, else (B,N,4).  deltas, out: (B,N,4).  variances: host pointer to
+ * 4 floats multiplied into the deltas first (models/faster_rcnn.py:149 / :79), or NULL. */
+int frcnn_decode_boxes(const float *anchors, int anchors_batched, const float *deltas,
+                       const float *variances, int64_t B, int64_t N, float *out,
+                       frcnn_stream_t stream);
+
+/* utils/bbox_utils.py:111-135 get_deltas_from_bboxes.  bboxes (N,4) or (B,N,4); gt_boxes, out
+ * (B,N,4).  div_variances: host pointer to 4 floats the result is divided by
+ * (utils/train_utils.py:200), or NULL. */
+int frcnn_encode_boxes(const float *bboxes, int bboxes_batched, const float *gt_boxes,
+                       const float *div_variances, int64_t B, int64_t N, float *out,
+                       frcnn_stream_t stream);
+
+/* ---- IoU ----------------------------------------------------------------------------- */
+/* utils/bbox_utils.py:138-160 generate_iou_map.  bboxes (N,4) or (B,N,4); gt (B,M,4);
+ * out (B,N,M), materialised. */
+int frcnn_iou_map(const float *bboxes, int bboxes_batched, const float *gt_boxes, int B, int N,
+                  int M, float *out, frcnn_stream_t stream);
+
+/* utils/train_utils.py:176-179: the IoU map fused with its three reductions, map never
+ * written.  max_iou (B,N) fp32, argmax_row (B,N) int32 (best gt per box), argmax_col (B,M)
+ * int32 (best box per gt).  Any output may be NULL.  Workspace: frcnn_iou_reduce_workspace_bytes. */
+size_t frcnn_iou_reduce_workspace_bytes(int B, int N, int M);
+int frcnn_iou_map_reduce(const float *bboxes, int bboxes_batched, const float *gt_boxes, int B,
+                         int N, int M, float *max_iou, int32_t *argmax_row, int32_t *argmax_col,
+                         void *workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
+/* ---- top-k --------------------------------------------------------------------------- */
+/* tf.nn.top_k(sorted=True) as used at models/faster_rcnn.py:153 and rpn_predictor.py:64:
+ * per row, K largest, descending, equal values by ascending index.  scores (B,N);
+ * out_values (B,K) and/or out_indices (B,K) (either may be NULL).  K > N is FRCNN_EINVAL. */
+int frcnn_top_k(const float *scores, int B, int N, int K, float *out_values,
+                int32_t *out_indices, frcnn_stream_t stream);
+
+/* ---- NMS ----------------------------------------------------------------------------- */
+/* utils/bbox_utils.py:60-83 non_max_suppression == tf.image.combined_non_max_suppression
+ * (pad_per_class=False).  boxes (B,n,q,4) with q==1 or q==c; scores (B,n,c).
+ * out_boxes (B,T,4), out_scores (B,T), out_classes (B,T) fp32, out_valid (B) int32, T=max_total.
+ * out_scores / out_classes / out_valid may be NULL. */
+size_t frcnn_combined_nms_workspace_bytes(int B, int n, int q, int c, int max_per_class,
+                                          int max_total);
+int frcnn_combined_nms(const float *boxes, const float *scores, int B, int n, int q, int c,
+                       int max_per_class, int max_total, float iou_threshold,
+                       float score_threshold, int clip_boxes, float *out_boxes,
+                       float *out_scores, float *out_classes, int32_t *out_valid,
+                       void *workspace, size_t workspace_bytes, frcnn_stream_t stream);
+
+/* ---- layers -------------------------------------------------------------------------- */
+/* models/faster_rcnn.py:130-166 RoIBBox.call, fused: variance scale + decode + per-image top-K
+ * + single-class greedy NMS + clip + zero pad.  deltas (B,N,4), scores (B,N), anchors (N,4),
+ * variances: host, 4 floats.  out_boxes (B,R,4); out_scores (B,R) and out_valid (B) optional. */
+size_t frcnn_roi_bbox_workspace_bytes(int B, int N, int K, int R);
+int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchors,
+                   const float *variances, int B, int N, int K, int R, float iou_threshold,
+                   float *out_boxes, float *out_scores, int32_t *out_valid, void *workspace,
+                   size_t workspace_bytes, frcnn_stream_t stream);
+
+/* tf.image.crop_and_resize(method="bilinear") as called at models/faster_rcnn.py:283-288.
+ * image (B,H,W,C); boxes (n,4); box_ind (n) int32, or NULL meaning box i belongs to image
+ * i / boxes_per_image (the RoIPooling layout, models/faster_rcnn.py:280-282).  out (n,ch,cw,C).
+ * An index outside [0,B) yields extrapolation_value rows (TF raises; the host wrapper checks). */
+int frcnn_crop_and_resize(const float *image, int B, int H, int W, int C, const float *boxes,
+                          const int32_t *box_ind, int n, int boxes_per_image, int crop_h,
+                          int crop_w, float extrapolation_value, float *out,
+                          frcnn_stream_t stream);
+
+/* models/faster_rcnn.py:63-91 Decoder.call, fused: per-class variance scale + decode,
+ * background-argmax masking, per-class NMS, cross-class top-T.  rois (B,R,4); deltas (B,R,L*4);
+ * probs (B,R,L).  out_boxes (B,T,4), out_labels (B,T) fp32, out_scores (B,T), out_valid (B)
+ * optional. */
+size_t frcnn_decoder_workspace_bytes(int B, int R, int L, int max_total);
+int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
+                  const float *variances, int B, int R, int L, int max_total,
+                  float score_threshold, float iou_threshold, float *out_boxes,
+                  float *out_labels, float *out_scores, int32_t *out_valid, void *workspace,
+                  size_t workspace_bytes, frcnn_stream_t stream);
+
+/* ---- RPN target assignment ----------------------------------------------------------- */
+/* utils/train_utils.py:72-88 randomly_select_xyz_mask with the random integers supplied by the
+ * caller (the reference draws them from TF's unseeded Philox stream).  mask (B,N) uint8;
+ * random_mask (B,N) int32; select: device int32, n_select == 1 or B entries.  out (B,N) uint8. */
+int frcnn_select_mask(const uint8_t *mask, const int32_t *random_mask, const int32_t *select,
+                      int n_select, int B, int N, uint8_t *out, frcnn_stream_t stream);
+
+/* utils/train_utils.py:149-202 calculate_rpn_actual_outputs.  anchors (N,4); gt_boxes (B,M,4);
+ * gt_labels (B,M) int32 (-1 = padding).  rnd_pos / rnd_neg: (B,N) int32 random integers of the
+ * two sampling calls, or both NULL to draw them in-kernel from `seed` (counter-based hash,
+ * U[1, 10*total_pos) and U[1, 10*(total_pos+total_neg))).  out_deltas (B,N,4); out_labels (B,N)
+ * fp32 in {-1,0,1} (== (B,G,G,A) in memory). */
+size_t frcnn_rpn_targets_workspace_bytes(int B, int N, int M);
+int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                      const int32_t *rnd_pos, const int32_t *rnd_neg, uint64_t seed, int B, int N,
+                      int M, int total_pos, int total_neg, const float *variances,
+                      float *out_deltas, float *out_labels, void *workspace,
+                      size_t workspace_bytes, frcnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

@@ -1,0 +1,141 @@
+"""ctypes binding of ``libfrcnn_hip.so`` (declared in ``include/frcnn_hip.h``).
+
+PyTorch-ROCm is used for exactly three things here: device allocation, the current HIP stream and
+DLPack import.  All arithmetic happens in the hand-written HIP kernels behind the C ABI.  There is
+no CPU fallback: if the shared library or a GPU is missing every entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+import torch  # must be imported before the library so both share one HIP runtime (libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfrcnn_hip.so")
+
+FRCNN_OK = 0
+FRCNN_EINVAL = -1
+FRCNN_EUNSUPPORTED = -2
+FRCNN_EHIP = -3
+
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/frcnn_hip.h one to one.
+SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
+    "frcnn_version": (_i, []),
+    "frcnn_last_error": (ctypes.c_char_p, []),
+    "frcnn_generate_anchors": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "frcnn_decode_boxes": (_i, [_vp, _i, _vp, _c_float_p, _i64, _i64, _vp, _vp]),
+    "frcnn_encode_boxes": (_i, [_vp, _i, _vp, _c_float_p, _i64, _i64, _vp, _vp]),
+    "frcnn_iou_map": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "frcnn_iou_reduce_workspace_bytes": (_sz, [_i, _i, _i]),
+    "frcnn_iou_map_reduce": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_top_k": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "frcnn_combined_nms_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "frcnn_combined_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_roi_bbox_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "frcnn_roi_bbox": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_crop_and_resize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "frcnn_decoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "frcnn_decoder": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "frcnn_rpn_targets_workspace_bytes": (_sz, [_i, _i, _i]),
+    "frcnn_rpn_targets": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
+                               _vp, _sz, _vp]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load ``libfrcnn_hip.so``; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C tf-faster-rcnn_amd/csrc`). There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError here = header and library disagree
+            fn.restype = restype
+            fn.argtypes = list(argtypes)
+        _lib = handle
+    return _lib
+
+
+class UnsupportedSizeError(RuntimeError):
+    """A size beyond what the kernels are built for (FRCNN_EUNSUPPORTED)."""
+
+
+def check(rc: int) -> None:
+    """Turn a C-ABI return code into the exception the reference's TF op would have raised."""
+    if rc == FRCNN_OK:
+        return
+    msg = lib().frcnn_last_error().decode("utf-8", "replace")
+    if rc == FRCNN_EINVAL:
+        raise ValueError(msg)  # TF: InvalidArgumentError
+    if rc == FRCNN_EUNSUPPORTED:
+        raise UnsupportedSizeError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu() -> torch.device:
+    if not torch.cuda.is_available():
+        raise RuntimeError("tf-faster-rcnn_amd needs a ROCm GPU (MI355X / gfx950); there is no CPU fallback.")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def device_tensor(x: Any, dtype: torch.dtype, device: Optional[torch.device] = None) -> torch.Tensor:
+    """Return ``x`` as a contiguous device tensor of ``dtype`` (DLPack objects are imported zero-copy)."""
+    if not isinstance(x, torch.Tensor):
+        if hasattr(x, "__dlpack__"):
+            x = torch.from_dlpack(x)
+        else:
+            x = torch.as_tensor(x)
+    if device is None:
+        device = x.device if x.is_cuda else require_gpu()
+    if x.device != device:
+        x = x.to(device)
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    return x.contiguous()
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def float4(values: Sequence[float]):
+    """Host array of 4 floats (the variances), rounded to fp32 like a TF constant."""
+    vals = [float(v) for v in values]
+    if len(vals) != 4:
+        raise ValueError(f"expected 4 variances, got {len(vals)}")
+    return (ctypes.c_float * 4)(*vals)
+
+
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Scratch buffer cached per (device, stream); stream-ordered reuse is race free."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device))
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,193 @@
+// crop_resize.hip -- bilinear crop_and_resize (RoI pooling), the byte-heaviest kernel of the path.
+//
+// Replaces tf.image.crop_and_resize as called at models/faster_rcnn.py:283-288.
+//
+// Roofline: HBM-write bound.  Per box the kernel writes ch*cw*C*4 bytes (33.9 MB per image at
+// R=300, 7x7, C=576) and reads one feature map per image (2.36 MB), i.e. 36,234,096 algorithmic
+// bytes per image at BASELINE config 2.
+//
+// Mapping:
+//   - one 256-thread workgroup per box; the output crop of a box is one contiguous run of
+//     ch*cw*C floats, so lane e of the block stores float4 number e, e+256, ... : every store is
+//     a full 1 KiB wave line, written once with the nontemporal hint so the streamed output does not
+//     evict the feature map from L2;
+//   - the 4 bilinear taps of an output pixel are 16 B-per-lane loads from the image's feature
+//     map, which stays resident in the XCD's 4 MiB L2: workgroups are remapped so that one XCD
+//     (blockIdx % 8) walks a contiguous range of boxes, i.e. one or two images at a time;
+//   - per-pixel sampling parameters (tap offsets, lerp weights) are computed once per box by the
+//     first ch*cw lanes and broadcast through LDS.
+//
+// Numerics: the sampling coordinates and the three lerps are evaluated in exactly the TF
+// kernel's operation order, one rounding per operation (build has contraction off).
+#include "common.hpp"
+
+namespace frcnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct __attribute__((aligned(16))) PixParam {
+  int off_tl, off_tr, off_bl, off_br;  // tap offsets in units of VEC floats, relative to the image
+  float lx, ly;
+  int valid;
+  int pad;
+};
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+  typedef f32x4 type;
+};
+template <>
+struct VecT<1> {
+  typedef float type;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void crop_resize_kernel(
+    const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, int n, int boxes_per_image, int ch, int cw, float extrap,
+    float *__restrict__ out) {
+  typedef typename VecT<VEC>::type vec_t;
+  __shared__ PixParam pp[256];
+
+  // XCD-aware remap: blocks b, b+8, b+16, ... share an XCD (and its L2); give each of the 8
+  // groups a contiguous range of boxes so that it works through one image's feature map at a time.
+  const int tid = threadIdx.x;
+  const int grp = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int q = n >> 3, r = n & 7;
+  const int start = (grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q;
+  const int box = start + slot;
+
+  const int bimg = box_ind ? box_ind[box] : (box / boxes_per_image);
+  const bool img_ok = (bimg >= 0) && (bimg < B);
+  const float y1 = boxes[(long long)box * 4 + 0];
+  const float x1 = boxes[(long long)box * 4 + 1];
+  const float y2 = boxes[(long long)box * 4 + 2];
+  const float x2 = boxes[(long long)box * 4 + 3];
+
+  const int CV = C / VEC;
+  const int P = ch * cw;
+  const vec_t *__restrict__ img =
+      reinterpret_cast<const vec_t *>(image + (long long)(img_ok ? bimg : 0) * H * W * C);
+
+  for (int p0 = 0; p0 < P; p0 += 256) {
+    const int np = (P - p0 < 256) ? (P - p0) : 256;
+    if (p0 > 0) __syncthreads();
+    if (tid < np) {
+      const int p = p0 + tid;
+      const int y = p / cw;
+      const int x = p - y * cw;
+      const float hm1 = (float)(H - 1), wm1 = (float)(W - 1);
+      float in_y, in_x;
+      if (ch > 1) {
+        float t = y2 - y1;
+        t = t * hm1;
+        const float hs = t / (float)(ch - 1);
+        const float t0 = y1 * hm1;
+        const float t1 = (float)y * hs;
+        in_y = t0 + t1;
+      } else {
+        float t0 = y1 + y2;
+        t0 = 0.5f * t0;
+        in_y = t0 * hm1;
+      }
+      if (cw > 1) {
+        float t = x2 - x1;
+        t = t * wm1;
+        const float ws = t / (float)(cw - 1);
+        const float t0 = x1 * wm1;
+        const float t1 = (float)x * ws;
+        in_x = t0 + t1;
+      } else {
+        float t0 = x1 + x2;
+        t0 = 0.5f * t0;
+        in_x = t0 * wm1;
+      }
+      const bool ok = img_ok && (in_y >= 0.0f) && (in_y <= hm1) && (in_x >= 0.0f) && (in_x <= wm1);
+      PixParam prm;
+      if (ok) {
+        const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
+        const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
+        prm.ly = in_y - (float)top;
+        prm.lx = in_x - (float)left;
+        prm.off_tl = (top * W + left) * CV;
+        prm.off_tr = (top * W + right) * CV;
+        prm.off_bl = (bot * W + left) * CV;
+        prm.off_br = (bot * W + right) * CV;
+        prm.valid = 1;
+      } else {
+        prm.ly = 0.0f;
+        prm.lx = 0.0f;
+        prm.off_tl = prm.off_tr = prm.off_bl = prm.off_br = 0;
+        prm.valid = 0;
+      }
+      prm.pad = 0;
+      pp[tid] = prm;
+    }
+    __syncthreads();
+
+    const int total = np * CV;
+    vec_t *__restrict__ dst = reinterpret_cast<vec_t *>(out + ((long long)box * P + p0) * C);
+    int p = tid / CV;
+    int c = tid - p * CV;
+    const int dp = 256 / CV, dc = 256 - dp * CV;
+#pragma unroll 4
+    for (int e = tid; e < total; e += 256) {
+      const PixParam prm = pp[p];
+      const vec_t tl = img[prm.off_tl + c];
+      const vec_t tr = img[prm.off_tr + c];
+      const vec_t bl = img[prm.off_bl + c];
+      const vec_t br = img[prm.off_br + c];
+      vec_t t = tr - tl;
+      t = t * prm.lx;
+      const vec_t tp = tl + t;
+      t = br - bl;
+      t = t * prm.lx;
+      const vec_t bt = bl + t;
+      t = bt - tp;
+      t = t * prm.ly;
+      vec_t v = tp + t;
+      if (!prm.valid) v = (vec_t)(extrap);
+      __builtin_nontemporal_store(v, &dst[e]);
+      c += dc;
+      p += dp;
+      if (c >= CV) {
+        c -= CV;
+        ++p;
+      }
+    }
+  }
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, int C,
+                                     const float *boxes, const int32_t *box_ind, int n,
+                                     int boxes_per_image, int crop_h, int crop_w,
+                                     float extrapolation_value, float *out,
+                                     frcnn_stream_t stream) {
+  FRCNN_REQUIRE(image && boxes && out, "crop_and_resize: null pointer");
+  FRCNN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "crop_and_resize: image shape (%d,%d,%d,%d) must be positive", B, H, W, C);
+  FRCNN_REQUIRE(crop_h > 0 && crop_w > 0, "crop_and_resize: crop size (%d,%d) must be positive", crop_h, crop_w);
+  FRCNN_REQUIRE(n >= 0, "crop_and_resize: negative box count");
+  FRCNN_REQUIRE(box_ind || boxes_per_image > 0, "crop_and_resize: box_ind is NULL and boxes_per_image <= 0");
+  FRCNN_REQUIRE((long long)H * W * C < (1ll << 31), "crop_and_resize: one image must hold fewer than 2^31 floats");
+  FRCNN_REQUIRE((long long)crop_h * crop_w < (1ll << 24), "crop_and_resize: crop too large");
+  if (n == 0) return FRCNN_OK;
+  const bool vec4 = (C % 4 == 0) && aligned_to(image, 16) && aligned_to(out, 16);
+  dim3 grid((unsigned)n), block(256);
+  if (vec4) {
+    hipLaunchKernelGGL(crop_resize_kernel<4>, grid, block, 0, (hipStream_t)stream, image, B, H, W,
+                       C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value,
+                       out);
+  } else {
+    hipLaunchKernelGGL(crop_resize_kernel<1>, grid, block, 0, (hipStream_t)stream, image, B, H, W,
+                       C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value,
+                       out);
+  }
+  return check_launch("crop_and_resize");
+}

@@ -1,0 +1,297 @@
+// rpn_targets.hip -- RPN target assignment: random mask sub-sampling and the target tail.
+//
+// Replaces utils/train_utils.py:72-88 (randomly_select_xyz_mask) and :180-202 (the part of
+// calculate_rpn_actual_outputs after the IoU reductions, which live in iou_map.hip).
+//
+// randomly_select_xyz_mask keeps, per image, the masked elements whose position in the descending
+// argsort of key = mask * random_int is below `select` (ties: lower index first).  Two full-row
+// argsorts are replaced by a SELECTION: a 4x8-bit radix select over the N keys (LDS histogram) finds
+// the key T of rank `select`; elements with key > T are in, elements with key == T are in while their
+// index-ordered rank among equals is below the remainder.  The result is identical to the argsort
+// formulation for every input, including ties and random integers <= 0.
+//
+// One 1024-thread workgroup per image; the per-anchor inputs (max IoU, random ints) are re-read from
+// global memory in each radix pass (36 KB per image, L2 resident) instead of being held in LDS, which
+// only keeps three N-bit maps.  Latency bound: ~0.3 MB of traffic per image.
+#include "common.hpp"
+
+namespace frcnn {
+
+static const int kTNT = 1024;
+static const int kTNW = 16;
+
+// ascending-order key: smaller = better (larger signed int first)
+__device__ __forceinline__ uint32_t inv_key(int key) { return ~(((uint32_t)key) ^ 0x80000000u); }
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// In-kernel stand-in for tf.random.uniform(minval=1, maxval=maxval, dtype=int32) (train_utils.py:83).
+__device__ __forceinline__ int draw_int(uint64_t seed, uint32_t stream, int b, int n, int maxval) {
+  const uint64_t h = mix64(mix64(seed ^ ((uint64_t)stream << 56)) + ((uint64_t)(uint32_t)b << 32) + (uint32_t)n);
+  const uint32_t span = (maxval > 2) ? (uint32_t)(maxval - 1) : 1u;
+  return 1 + (int)((h >> 32) % span);
+}
+
+// Workgroup-cooperative selection.  keyf(n) -> int key (= mask * random); emit(n, in) is called once
+// for every n < N with in == (rank of n in the descending key order, ties by index) < S.
+// hist: 256 uint32 in LDS; misc: 8 ints in LDS; wsum: kTNW ints in LDS.
+template <class KeyF, class EmitF>
+__device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t *hist, int *misc, int *wsum,
+                                               EmitF emit) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (S <= 0 || S >= N) {  // uniform: nobody / everybody has rank < S
+    const bool in = (S >= N) && (S > 0);
+    for (int n = tid; n < N; n += kTNT) emit(n, in);
+    return;
+  }
+  uint32_t prefix = 0;
+  int need = S;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    __syncthreads();
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int n = tid; n < N; n += kTNT) {
+      const uint32_t k = inv_key(keyf(n));
+      if (pass == 3 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (w == 0) {
+      const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const uint32_t s4 = h0 + h1 + h2 + h3;
+      uint32_t inc = s4;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += t;
+      }
+      const uint32_t exc = inc - s4;
+      if ((exc < (uint32_t)need) && (inc >= (uint32_t)need)) {  // exactly one lane (S < N)
+        uint32_t cum = exc;
+        int d = 4 * lane;
+        if (cum + h0 < (uint32_t)need) {
+          cum += h0;
+          ++d;
+          if (cum + h1 < (uint32_t)need) {
+            cum += h1;
+            ++d;
+            if (cum + h2 < (uint32_t)need) {
+              cum += h2;
+              ++d;
+            }
+          }
+        }
+        misc[0] = (int)((prefix << 8) | (uint32_t)d);
+        misc[1] = need - (int)cum;
+      }
+    }
+    __syncthreads();
+    prefix = (uint32_t)misc[0];
+    need = misc[1];
+  }
+  const uint32_t T = prefix;
+  const int need_eq = need;
+  // ordered pass: index-ordered rank among the elements with key == T
+  int eq_before = 0;
+  for (int base = 0; base < N; base += kTNT) {
+    const int n = base + tid;
+    uint32_t k = 0xFFFFFFFFu;
+    bool live = n < N;
+    if (live) k = inv_key(keyf(n));
+    const bool eq = live && (k == T);
+    const unsigned long long bal = __ballot(eq);
+    __syncthreads();
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kTNW; ++i) {
+      const int s = wsum[i];
+      if (i < w) wbase += s;
+      tot += s;
+    }
+    if (live) {
+      const int eq_rank = eq_before + wbase + __popcll(bal & lanemask_lt());
+      emit(n, (k < T) || (eq && eq_rank < need_eq));
+    }
+    eq_before += tot;
+  }
+}
+
+// utils/train_utils.py:72-88, one image per workgroup.
+__global__ __launch_bounds__(1024) void select_mask_kernel(const uint8_t *__restrict__ mask,
+                                                           const int *__restrict__ rnd,
+                                                           const int *__restrict__ select, int n_select, int N,
+                                                           uint8_t *__restrict__ out) {
+  __shared__ uint32_t hist[256];
+  __shared__ int misc[8];
+  __shared__ int wsum[kTNW];
+  const int b = blockIdx.x;
+  const uint8_t *m = mask + (long long)b * N;
+  const int *r = rnd + (long long)b * N;
+  uint8_t *o = out + (long long)b * N;
+  const int S = select[n_select == 1 ? 0 : b];
+  select_largest([&](int n) { return (m[n] ? 1 : 0) * r[n]; }, N, S, hist, misc, wsum,
+                 [&](int n, bool in) { o[n] = (uint8_t)((m[n] != 0) && in); });
+}
+
+// utils/train_utils.py:180-202, one image per workgroup.  LDS: three N-bit maps.
+__global__ __launch_bounds__(1024) void rpn_targets_kernel(
+    const float *__restrict__ anchors, const float *__restrict__ gt_boxes, const int *__restrict__ gt_labels,
+    const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int N, int M,
+    int total_pos, int total_neg, float v0, float v1, float v2, float v3, const float *__restrict__ max_iou,
+    const int *__restrict__ argmax_row, const int *__restrict__ argmax_col, float *__restrict__ out_deltas,
+    float *__restrict__ out_labels) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t maps[];
+  __shared__ uint32_t hist[256];
+  __shared__ int misc[8];
+  __shared__ int wsum[kTNW];
+  __shared__ int s_pos_count;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int words = (N + 31) >> 5;
+  uint32_t *forced = maps;
+  uint32_t *pos_sel = maps + words;
+  uint32_t *neg_sel = maps + 2 * words;
+  const float *miou = max_iou + (long long)b * N;
+  const int *rp = rnd_pos ? rnd_pos + (long long)b * N : nullptr;
+  const int *rn = rnd_neg ? rnd_neg + (long long)b * N : nullptr;
+
+  for (int i = tid; i < 3 * words; i += kTNT) maps[i] = 0u;
+  if (tid == 0) s_pos_count = 0;
+  __syncthreads();
+  // :181-188 every valid gt forces its best anchor positive
+  for (int m = tid; m < M; m += kTNT) {
+    if (gt_labels[(long long)b * M + m] != -1) {
+      const int a = argmax_col[(long long)b * M + m];
+      if (a >= 0 && a < N) atomicOr(&forced[a >> 5], 1u << (a & 31));
+    }
+  }
+  __syncthreads();
+
+  // :180,:188-189 positives, sub-sampled to total_pos
+  auto pos_key = [&](int n) -> int {
+    const bool msk = (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u);
+    const int r = rp ? rp[n] : draw_int(seed, 0u, b, n, 10 * total_pos);
+    return (msk ? 1 : 0) * r;
+  };
+  select_largest(pos_key, N, total_pos, hist, misc, wsum, [&](int n, bool in) {
+    const bool msk = (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u);
+    if (msk && in) {
+      atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
+      atomicAdd(&s_pos_count, 1);
+    }
+  });
+  __syncthreads();
+  // :190-191
+  const int neg_count = (total_pos + total_neg) - s_pos_count;
+
+  // :193-194 negatives, sub-sampled to neg_count
+  auto neg_key = [&](int n) -> int {
+    const bool msk = (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u);
+    const int r = rn ? rn[n] : draw_int(seed, 1u, b, n, 10 * (total_pos + total_neg));
+    return (msk ? 1 : 0) * r;
+  };
+  select_largest(neg_key, N, neg_count, hist, misc, wsum, [&](int n, bool in) {
+    const bool msk = (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u);
+    if (msk && in) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
+  });
+  __syncthreads();
+
+  // :195-200 labels and regression targets
+  for (int n = tid; n < N; n += kTNT) {
+    const bool pos = (pos_sel[n >> 5] >> (n & 31)) & 1u;
+    const bool neg = (neg_sel[n >> 5] >> (n & 31)) & 1u;
+    const float pl = pos ? 1.0f : -1.0f;
+    const float nl = neg ? 1.0f : 0.0f;
+    out_labels[(long long)b * N + n] = pl + nl;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos && M > 0) {
+      const int m = argmax_row[(long long)b * N + n];
+      g = *reinterpret_cast<const float4 *>(gt_boxes + ((long long)b * M + m) * 4);
+    }
+    const float4 a = *reinterpret_cast<const float4 *>(anchors + (long long)n * 4);
+    float4 d = encode_box(a, g);
+    d.x = d.x / v0;
+    d.y = d.y / v1;
+    d.z = d.z / v2;
+    d.w = d.w / v3;
+    *reinterpret_cast<float4 *>(out_deltas + ((long long)b * N + n) * 4) = d;
+  }
+}
+
+static const int kMaxTargetsN = 262144;
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" {
+
+int frcnn_select_mask(const uint8_t *mask, const int32_t *random_mask, const int32_t *select,
+                      int n_select, int B, int N, uint8_t *out, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(mask && random_mask && select && out, "select_mask: null pointer");
+  FRCNN_REQUIRE(B >= 0 && N >= 0, "select_mask: negative shape");
+  FRCNN_REQUIRE(n_select == 1 || n_select == B, "select_mask: select_xyz must have 1 or batch_size (%d) entries, got %d", B, n_select);
+  if (B == 0 || N == 0) return FRCNN_OK;
+  hipLaunchKernelGGL(select_mask_kernel, dim3((unsigned)B), dim3(kTNT), 0, (hipStream_t)stream, mask, random_mask,
+                     select, n_select, N, out);
+  return check_launch("select_mask");
+}
+
+size_t frcnn_rpn_targets_workspace_bytes(int B, int N, int M) {
+  if (B < 0 || N < 0 || M < 0) return 0;
+  size_t off = 0;
+  off += round_up((size_t)B * N * 4, 256);                      // max_iou
+  off += round_up((size_t)B * N * 4, 256);                      // argmax_row
+  off += round_up((size_t)B * (M > 0 ? M : 1) * 4, 256);        // argmax_col
+  off += frcnn_iou_reduce_workspace_bytes(B, N, M > 0 ? M : 1); // column keys
+  return off + 256;
+}
+
+int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                      const int32_t *rnd_pos, const int32_t *rnd_neg, uint64_t seed, int B, int N,
+                      int M, int total_pos, int total_neg, const float *variances,
+                      float *out_deltas, float *out_labels, void *workspace,
+                      size_t workspace_bytes, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(anchors && gt_boxes && gt_labels && variances && out_deltas && out_labels, "rpn_targets: null pointer");
+  FRCNN_REQUIRE((rnd_pos == nullptr) == (rnd_neg == nullptr), "rpn_targets: give both random tensors or neither");
+  FRCNN_REQUIRE(B >= 0 && N > 0 && M > 0, "rpn_targets: bad shape B=%d N=%d M=%d", B, N, M);
+  FRCNN_REQUIRE(N <= kMaxTargetsN, "rpn_targets: N=%d anchors exceeds the limit %d", N, kMaxTargetsN);
+  FRCNN_REQUIRE(total_pos >= 0 && total_neg >= 0, "rpn_targets: negative sample counts");
+  FRCNN_REQUIRE(aligned_to(anchors, 16) && aligned_to(gt_boxes, 16) && aligned_to(out_deltas, 16),
+                "rpn_targets: box pointers must be 16-byte aligned");
+  FRCNN_REQUIRE(workspace && aligned_to(workspace, 256) && workspace_bytes >= frcnn_rpn_targets_workspace_bytes(B, N, M),
+                "rpn_targets: workspace must be non-null, 256-byte aligned and >= %zu bytes", frcnn_rpn_targets_workspace_bytes(B, N, M));
+  if (B == 0) return FRCNN_OK;
+  unsigned char *p = reinterpret_cast<unsigned char *>(workspace);
+  size_t off = 0;
+  float *max_iou = reinterpret_cast<float *>(p + off);
+  off += round_up((size_t)B * N * 4, 256);
+  int *argmax_row = reinterpret_cast<int *>(p + off);
+  off += round_up((size_t)B * N * 4, 256);
+  int *argmax_col = reinterpret_cast<int *>(p + off);
+  off += round_up((size_t)B * M * 4, 256);
+  void *keys = p + off;
+  const size_t keys_bytes = frcnn_iou_reduce_workspace_bytes(B, N, M);
+  int rc = frcnn_iou_map_reduce(anchors, 0, gt_boxes, B, N, M, max_iou, argmax_row, argmax_col, keys, keys_bytes, stream);
+  if (rc) return rc;
+  const int words = (N + 31) >> 5;
+  const size_t lds = (size_t)3 * words * 4;
+  auto kern = rpn_targets_kernel;
+  if (lds > 48 * 1024) {
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                   "rpn_targets: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTNT), lds, (hipStream_t)stream, anchors, gt_boxes, gt_labels, rnd_pos,
+                     rnd_neg, (unsigned long long)seed, N, M, total_pos, total_neg, variances[0], variances[1],
+                     variances[2], variances[3], max_iou, argmax_row, argmax_col, out_deltas, out_labels);
+  return check_launch("rpn_targets");
+}
+
+}  // extern "C"

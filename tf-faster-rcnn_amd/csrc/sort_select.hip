@@ -1,0 +1,329 @@
+// sort_select.hip -- per-segment threshold / radix-select / stable radix sort of scores.
+//
+// Replaces tf.nn.top_k (models/faster_rcnn.py:153) and the score-ordered candidate queue inside
+// tf.image.combined_non_max_suppression (utils/bbox_utils.py:79): for every segment (image, class)
+// the elements whose score passes the threshold are ordered by (score descending, index
+// ascending) and the first K of them are emitted.
+//
+// One 1024-thread workgroup (16 waves) per segment; everything after the first read of the scores
+// happens in LDS (up to ~144 KB of the CU's 160 KB):
+//   1. if the segment has more elements than fit, a 4x8-bit radix SELECT over the scores (LDS
+//      histogram, global re-reads that stay in L2) finds the key of the K-th best element;
+//   2. the surviving elements are compacted into LDS in index order (blocked prefix scan), keyed by
+//      ~order_key(score) so that ascending key == descending score;
+//   3. a 4-pass, 8-bit, least-significant-digit radix sort permutes 16-bit slot numbers.  Stability
+//      is what yields "equal scores by ascending index": each wave owns a contiguous slice of the
+//      current order, counts its digits with LDS adds, the 256x16 counters are scanned digit-major /
+//      wave-minor, and each 64-element chunk ranks itself with an 8-ballot match of equal digits.
+// The kernel is latency bound (a few tens of KB per segment); its job is to stay off the host and
+// out of HBM, not to saturate bandwidth.
+#include "sort_select.hpp"
+
+namespace frcnn {
+
+static const int kNT = 1024;
+static const int kNW = 16;
+
+// Exclusive scan of one int per thread over the 1024-thread block; total returned to every thread.
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // wsum may still be read from a previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kNW; ++i) {
+    int s = wsum[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + inc - v;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int c, int n, int K, int use_thr,
+                                                           float thr, int slots, int do_select,
+                                                           int *__restrict__ sorted_idx,
+                                                           float *__restrict__ sorted_val,
+                                                           int *__restrict__ counts, int out_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                 // [slots]
+  uint32_t *hist = keys + slots;                                       // [kNW*256]
+  int *wsum = reinterpret_cast<int *>(hist + kNW * 256);               // [32]
+  int *misc = wsum + 32;                                               // [32]
+  IdxT *orig = reinterpret_cast<IdxT *>(misc + 32);                    // [slots]
+  uint16_t *permA = reinterpret_cast<uint16_t *>(orig + slots);        // [slots]
+  uint16_t *permB = permA + slots;                                     // [slots]
+
+  const int seg = blockIdx.x;
+  const int b = seg / c;
+  const int cls = seg - b * c;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+  if (K <= 0 || n <= 0) {
+    if (tid == 0 && counts) counts[seg] = 0;
+    return;
+  }
+
+  // ---- 1. radix select of the K-th smallest key (only when the segment does not fit) ---------
+  uint32_t T = 0xFFFFFFFFu;
+  int need_eq = 0;
+  bool filter = false;  // true: keep key < T, and the first need_eq elements with key == T
+  if (do_select) {
+    if (tid == 0) misc[2] = 0;
+    uint32_t prefix = 0;
+    int need = K;
+    bool all = false;
+    for (int pass = 3; pass >= 0; --pass) {
+      const int shift = pass * 8;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += kNT) {
+        const float s = load_score(src, b, i, cls);
+        if (!use_thr || s > thr) {
+          const uint32_t k = ~f_order_key(s);
+          if (pass == 3 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+      }
+      __syncthreads();
+      if (w == 0) {
+        const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const uint32_t s4 = h0 + h1 + h2 + h3;
+        uint32_t inc = s4;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+          if (lane >= off) inc += t;
+        }
+        const uint32_t exc = inc - s4;
+        const bool here = (exc < (uint32_t)need) && (inc >= (uint32_t)need);
+        const unsigned long long bal = __ballot(here);
+        if (bal == 0ull) {
+          if (lane == 0) misc[2] = 1;  // fewer than K candidates in total: keep them all
+        } else if (here) {
+          uint32_t cum = exc;
+          int d = 4 * lane;
+          if (cum + h0 < (uint32_t)need) {
+            cum += h0;
+            ++d;
+            if (cum + h1 < (uint32_t)need) {
+              cum += h1;
+              ++d;
+              if (cum + h2 < (uint32_t)need) {
+                cum += h2;
+                ++d;
+              }
+            }
+          }
+          misc[0] = (int)((prefix << 8) | (uint32_t)d);
+          misc[1] = need - (int)cum;
+        }
+      }
+      __syncthreads();
+      if (misc[2]) {
+        all = true;
+        break;
+      }
+      prefix = (uint32_t)misc[0];
+      need = misc[1];
+    }
+    if (!all) {
+      filter = true;
+      T = prefix;
+      need_eq = need;
+    }
+    __syncthreads();
+  }
+
+  // ---- 2. stable compaction into LDS: thread t owns elements [t*E, (t+1)*E) ---------------------
+  const int E = (n + kNT - 1) / kNT;
+  const int i0 = tid * E;
+  const int i1 = (i0 + E < n) ? (i0 + E) : n;
+  int cnt = 0, eqc = 0;
+  for (int i = i0; i < i1; ++i) {
+    const float s = load_score(src, b, i, cls);
+    if (!use_thr || s > thr) {
+      const uint32_t k = ~f_order_key(s);
+      if (!filter || k < T)
+        ++cnt;
+      else if (k == T)
+        ++eqc;
+    }
+  }
+  int eq_base = 0, tot = 0;
+  if (filter) eq_base = block_excl_scan(eqc, wsum, tot);
+  int sel_eq = 0;
+  if (filter) {
+    sel_eq = need_eq - eq_base;
+    sel_eq = sel_eq < 0 ? 0 : (sel_eq > eqc ? eqc : sel_eq);
+  }
+  int V = 0;
+  int pos = block_excl_scan(cnt + sel_eq, wsum, V);
+  // V <= slots by construction (no filter: V <= n == slots; filter: V == K == slots).
+  {
+    int eq_seen = 0;
+    for (int i = i0; i < i1; ++i) {
+      const float s = load_score(src, b, i, cls);
+      if (!use_thr || s > thr) {
+        const uint32_t k = ~f_order_key(s);
+        bool take = !filter || k < T;
+        if (filter && k == T) {
+          take = (eq_seen < sel_eq);
+          ++eq_seen;
+        }
+        if (take && pos < slots) {
+          keys[pos] = k;
+          orig[pos] = (IdxT)i;
+          permA[pos] = (uint16_t)pos;
+          ++pos;
+        }
+      }
+    }
+  }
+  if (V > slots) V = slots;  // defensive; cannot happen
+
+  // ---- 3. stable LSD radix sort of the V slots --------------------------------------------------
+  const int nchunks = (V + 63) >> 6;
+  const int cpw = (nchunks + kNW - 1) / kNW;
+  const int c0 = w * cpw;
+  const int c1 = (c0 + cpw < nchunks) ? (c0 + cpw) : nchunks;
+  volatile uint32_t *vhist = hist;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
+    __syncthreads();  // also publishes keys/orig/permA on the first pass
+    for (int ch = c0; ch < c1; ++ch) {
+      const int p = (ch << 6) + lane;
+      if (p < V) {
+        const uint32_t d = (keys[permA[p]] >> shift) & 255u;
+        atomicAdd(&hist[d * kNW + w], 1u);
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t a0 = hist[4 * tid], a1 = hist[4 * tid + 1], a2 = hist[4 * tid + 2], a3 = hist[4 * tid + 3];
+      int total;
+      const int ex = block_excl_scan((int)(a0 + a1 + a2 + a3), wsum, total);
+      hist[4 * tid] = (uint32_t)ex;
+      hist[4 * tid + 1] = (uint32_t)ex + a0;
+      hist[4 * tid + 2] = (uint32_t)ex + a0 + a1;
+      hist[4 * tid + 3] = (uint32_t)ex + a0 + a1 + a2;
+    }
+    __syncthreads();
+    for (int ch = c0; ch < c1; ++ch) {
+      const int p = (ch << 6) + lane;
+      const bool valid = p < V;
+      const uint32_t id = valid ? (uint32_t)permA[p] : 0u;
+      const uint32_t d = (keys[id] >> shift) & 255u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool on = (d >> bit) & 1u;
+        const unsigned long long bm = __ballot(on);
+        peers &= on ? bm : ~bm;
+      }
+      if (valid) {
+        const uint32_t base = vhist[d * kNW + w];
+        const int r = __popcll(peers & lanemask_lt());
+        permB[base + (uint32_t)r] = (uint16_t)id;
+        if (r == 0) vhist[d * kNW + w] = base + (uint32_t)__popcll(peers);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    uint16_t *t = permA;
+    permA = permB;
+    permB = t;
+  }
+
+  // ---- 4. emit ------------------------------------------------------------------------------------
+  const int nout = (V < K) ? V : K;
+  for (int r = tid; r < nout; r += kNT) {
+    const int i = (int)orig[permA[r]];
+    sorted_idx[(long long)seg * out_stride + r] = i;
+    if (sorted_val) sorted_val[(long long)seg * out_stride + r] = load_score(src, b, i, cls);
+  }
+  if (tid == 0 && counts) counts[seg] = nout;
+}
+
+static size_t sort_lds_bytes(int slots, size_t idx_bytes) {
+  return (size_t)slots * (4 + idx_bytes + 4) + (size_t)kNW * 256 * 4 + 64 * 4;
+}
+
+int launch_sort_select(const ScoreSource &src, int B, int c, int n, int K, bool use_thr, float thr,
+                       int *sorted_idx, float *sorted_val, int *counts, int out_stride,
+                       hipStream_t stream) {
+  if (B <= 0 || c <= 0) return FRCNN_OK;
+  const bool idx16 = n <= 65536;
+  const int cap = idx16 ? kSortCap16 : kSortCap32;
+  const int keff = K < n ? K : n;
+  int do_select = 0;
+  int slots;
+  if (n <= cap) {
+    slots = n;
+  } else {
+    if (keff > cap)
+      return set_error(FRCNN_EUNSUPPORTED,
+                       "sort_select: %d candidates to keep out of %d elements exceeds the in-LDS sort capacity %d",
+                       keff, n, cap);
+    do_select = 1;
+    slots = keff;
+  }
+  slots = (slots + 7) & ~7;  // keep the sub-arrays 16-byte aligned
+  if (slots < 8) slots = 8;
+  const size_t lds = sort_lds_bytes(slots, idx16 ? 2 : 4);
+  if (lds > 160 * 1024) return set_error(FRCNN_EUNSUPPORTED, "sort_select: %zu bytes of LDS needed", lds);
+  const long long nseg = (long long)B * c;
+  if (nseg >= (1ll << 31)) return set_error(FRCNN_EINVAL, "sort_select: too many segments");
+  dim3 grid((unsigned)nseg), block(kNT);
+  if (idx16) {
+    auto kern = sort_select_kernel<uint16_t>;
+    if (lds > 48 * 1024) {
+      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                         "sort_select: hipFuncSetAttribute");
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, src, c, n, keff, use_thr ? 1 : 0, thr, slots, do_select,
+                       sorted_idx, sorted_val, counts, out_stride);
+  } else {
+    auto kern = sort_select_kernel<uint32_t>;
+    if (lds > 48 * 1024) {
+      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                         "sort_select: hipFuncSetAttribute");
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, src, c, n, keff, use_thr ? 1 : 0, thr, slots, do_select,
+                       sorted_idx, sorted_val, counts, out_stride);
+  }
+  return check_launch("sort_select");
+}
+
+}  // namespace frcnn
+
+using namespace frcnn;
+
+extern "C" int frcnn_top_k(const float *scores, int B, int N, int K, float *out_values,
+                           int32_t *out_indices, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(scores, "top_k: null scores");
+  FRCNN_REQUIRE(B >= 0 && N >= 0 && K >= 0, "top_k: negative shape");
+  FRCNN_REQUIRE(K <= N, "top_k: input must have at least k columns (k=%d, columns=%d)", K, N);
+  FRCNN_REQUIRE(out_indices, "top_k: out_indices must not be NULL");
+  if (B == 0 || K == 0) return FRCNN_OK;
+  ScoreSource src;
+  src.scores = scores;
+  src.stride_b = N;
+  src.elem_stride = 1;
+  src.mask_bg = 0;
+  src.L = 0;
+  return launch_sort_select(src, B, 1, N, K, false, 0.0f, out_indices, out_values, nullptr, K,
+                            (hipStream_t)stream);
+}

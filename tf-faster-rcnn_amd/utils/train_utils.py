@@ -1,0 +1,159 @@
+"""Training-time helpers on the proposal path -- drop-in for the reference's ``utils/train_utils.py``.
+
+Covers the hyper-parameter table, ``randomly_select_xyz_mask`` and ``calculate_rpn_actual_outputs``.
+Losses, generators and the data pipeline are out of scope.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib
+
+HyperParams = Dict[str, Any]
+
+# reference utils/train_utils.py:17-30
+RPN: Dict[str, HyperParams] = {
+    "vgg16": {
+        "img_size": 500,
+        "feature_map_shape": 31,
+        "anchor_ratios": [1., 2., 1. / 2.],
+        "anchor_scales": [128, 256, 512],
+    },
+    "mobilenet_v2": {
+        "img_size": 500,
+        "feature_map_shape": 32,
+        "anchor_ratios": [1., 2., 1. / 2.],
+        "anchor_scales": [128, 256, 512],
+    }
+}
+
+
+def get_hyper_params(backbone: str, **kwargs: Any) -> HyperParams:
+    """Hyper-parameter dictionary for ``backbone``.  Mirrors reference ``utils/train_utils.py:33-56``:
+    a copy of the backbone defaults, the shared defaults, then overrides that apply only to keys that
+    already exist and whose new value is truthy; unknown backbones raise ``KeyError``.
+    """
+    hyper_params = dict(RPN[backbone])
+    hyper_params["pre_nms_topn"] = 6000
+    hyper_params["train_nms_topn"] = 1500
+    hyper_params["test_nms_topn"] = 300
+    hyper_params["nms_iou_threshold"] = 0.7
+    hyper_params["total_pos_bboxes"] = 128
+    hyper_params["total_neg_bboxes"] = 128
+    hyper_params["pooling_size"] = (7, 7)
+    hyper_params["variances"] = [0.1, 0.1, 0.2, 0.2]
+    for key, value in kwargs.items():
+        if key in hyper_params and value:
+            hyper_params[key] = value
+    hyper_params["anchor_count"] = len(hyper_params["anchor_ratios"]) * len(hyper_params["anchor_scales"])
+    return hyper_params
+
+
+def get_step_size(total_items: int, batch_size: int) -> int:
+    """Steps needed to cover a dataset once (reference ``utils/train_utils.py:59-69``)."""
+    return math.ceil(total_items / batch_size)
+
+
+def randomly_select_xyz_mask(mask: torch.Tensor, select_xyz: Any,
+                             random_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Keep up to ``select_xyz`` true elements per batch row.  Mirrors reference
+    ``utils/train_utils.py:72-88``.
+
+    The reference multiplies the mask by ``tf.random.uniform([1, 10*max(select)), int32)`` and keeps the
+    elements whose rank in the descending argsort is below ``select`` (ties: lower index first).
+    TF's Philox stream cannot be reproduced, so the random integers may be passed in as
+    ``random_mask`` ``(batch, total_items)`` int32 (extra, optional argument); when omitted they are
+    drawn on the device with the same range.
+
+    Args:
+        mask: ``(batch, total_items)`` bool.
+        select_xyz: ``(1,)`` or ``(batch,)`` int32 (tensor, list or int).
+    """
+    m = _lib.device_tensor(mask, torch.bool)
+    device = m.device
+    if m.dim() != 2:
+        raise ValueError(f"mask must be (batch, total_items), got {tuple(m.shape)}")
+    B, N = m.shape
+    sel = _lib.device_tensor(select_xyz, torch.int32, device).reshape(-1)
+    if sel.numel() not in (1, B):
+        raise ValueError(f"select_xyz must have 1 or batch_size entries, got {sel.numel()}")
+    if random_mask is None:
+        maxval = int(sel.max().item()) * 10
+        if maxval <= 1:
+            raise ValueError("Need minval < maxval, got 1 >= %d" % maxval)  # tf.random.uniform's check
+        rnd = torch.randint(1, maxval, (B, N), dtype=torch.int32, device=device)
+    else:
+        rnd = _lib.device_tensor(random_mask, torch.int32, device)
+        if rnd.shape != m.shape:
+            raise ValueError("random_mask must have the shape of mask")
+    m8 = m.view(torch.uint8)
+    out = torch.empty((B, N), dtype=torch.uint8, device=device)
+    _lib.check(_lib.lib().frcnn_select_mask(_lib.ptr(m8), _lib.ptr(rnd), _lib.ptr(sel), sel.numel(), B, N,
+                                            _lib.ptr(out), _lib.stream_ptr(device)))
+    return out.view(torch.bool)
+
+
+def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torch.Tensor,
+                                 hyper_params: HyperParams,
+                                 random_masks: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                                 seed: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """RPN regression and classification targets for a batch.  Mirrors reference
+    ``utils/train_utils.py:149-202``: anchors x gt IoU, row/column argmax, positives (IoU > 0.7 or best
+    anchor of a valid gt) sampled to ``total_pos_bboxes``, negatives (IoU < 0.3) sampled to fill
+    ``total_pos + total_neg``, labels in {+1, 0, -1}, deltas of the positives divided by ``variances``.
+
+    Args:
+        anchors: ``(total_anchors, 4)``.
+        gt_boxes: ``(batch, padded_gt_boxes, 4)`` (zero padded).
+        gt_labels: ``(batch, padded_gt_boxes)`` int32 (``-1`` padded).
+        hyper_params: needs ``feature_map_shape``, ``anchor_count``, ``total_pos_bboxes``,
+            ``total_neg_bboxes``, ``variances``.
+        random_masks: optional ``(pos, neg)`` int32 tensors ``(batch, total_anchors)``: the random
+            integers of the two sampling calls (extra argument, for reproducibility/parity).
+        seed: seed of the in-kernel draw used when ``random_masks`` is omitted.
+
+    Returns:
+        ``bbox_deltas (batch, total_anchors, 4)`` and
+        ``bbox_labels (batch, feature_map_shape, feature_map_shape, anchor_count)``, both fp32.
+    """
+    anchors_t = _lib.device_tensor(anchors, torch.float32)
+    device = anchors_t.device
+    gt_t = _lib.device_tensor(gt_boxes, torch.float32, device)
+    lab_t = _lib.device_tensor(gt_labels, torch.int32, device)
+    feature_map_shape = int(hyper_params["feature_map_shape"])
+    anchor_count = int(hyper_params["anchor_count"])
+    total_pos = int(hyper_params["total_pos_bboxes"])
+    total_neg = int(hyper_params["total_neg_bboxes"])
+    variances = _lib.float4(hyper_params["variances"])
+    if anchors_t.dim() != 2 or anchors_t.shape[1] != 4:
+        raise ValueError(f"anchors must be (total_anchors, 4), got {tuple(anchors_t.shape)}")
+    if gt_t.dim() != 3 or gt_t.shape[2] != 4:
+        raise ValueError(f"gt_boxes must be (batch, padded_gt_boxes, 4), got {tuple(gt_t.shape)}")
+    B, M, _ = gt_t.shape
+    N = anchors_t.shape[0]
+    if lab_t.shape != (B, M):
+        raise ValueError("gt_labels must be (batch, padded_gt_boxes)")
+    if feature_map_shape * feature_map_shape * anchor_count != N:
+        raise ValueError("anchors do not match feature_map_shape**2 * anchor_count")  # the reference's reshape fails
+    rp = rn = None
+    if random_masks is not None:
+        rp = _lib.device_tensor(random_masks[0], torch.int32, device)
+        rn = _lib.device_tensor(random_masks[1], torch.int32, device)
+        if rp.shape != (B, N) or rn.shape != (B, N):
+            raise ValueError("random_masks must be two (batch, total_anchors) tensors")
+    if seed is None:
+        # a fresh draw per call, like the reference's unseeded tf.random.uniform (host RNG, no device sync)
+        seed = 0 if random_masks is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+    deltas = torch.empty((B, N, 4), dtype=torch.float32, device=device)
+    labels = torch.empty((B, N), dtype=torch.float32, device=device)
+    L = _lib.lib()
+    nbytes = L.frcnn_rpn_targets_workspace_bytes(B, N, M)
+    ws = _lib.workspace(nbytes, device)
+    _lib.check(L.frcnn_rpn_targets(_lib.ptr(anchors_t), _lib.ptr(gt_t), _lib.ptr(lab_t), _lib.ptr(rp), _lib.ptr(rn),
+                                   int(seed) & 0xFFFFFFFFFFFFFFFF, B, N, M, total_pos, total_neg, variances,
+                                   _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
+    return deltas, labels.reshape(B, feature_map_shape, feature_map_shape, anchor_count)
