@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s through the proposal/RoI hot path (BASELINE.json metric).
+
+One step = RoIBBox (decode + top-6000 + NMS -> 300 RoIs) -> RoIPooling (7x7 crop_and_resize)
+-> Decoder (per-class NMS) over one batch of 16 synthetic images (BASELINE config 2:
+mobilenet_v2, 500x500 -> 32x32x576 feature map, 9216 anchors, 21 labels), inputs resident in HBM.
+The conv backbone and the dense heads are out of scope: their outputs are synthetic tensors.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: pure data parallel over images, one process per GPU, every rank runs its own batch of 16
+(weak scaling), no collective on the data path; torch.distributed is used only for the barrier and
+the max-over-ranks time.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+# BASELINE config 2
+CFG = dict(backbone="mobilenet_v2", B=16, G=32, C=576, K=6000, R=300, L=21, pool=7)
+
+
+def crop_bytes_per_image(cfg) -> int:
+    """Algorithmic bytes of crop_and_resize per image: write R*49*C*4, read H*W*C*4 + R*20."""
+    return cfg["R"] * cfg["pool"] * cfg["pool"] * cfg["C"] * 4 + cfg["G"] * cfg["G"] * cfg["C"] * 4 + cfg["R"] * 20
+
+
+def make_inputs(cfg, seed):
+    deltas, scores = synth.rpn_outputs(seed, cfg["B"], cfg["G"])
+    fm = synth.feature_map(seed, cfg["B"], cfg["G"], cfg["C"])
+    hd, hp = synth.head_outputs(seed, cfg["B"], cfg["R"], cfg["L"])
+    return deltas, scores, fm, hd, hp
+
+
+def cpu_baseline(cfg, inputs, hyper, min_seconds=10.0):
+    """The CPU oracle (reference-semantics restatement) on the host cores: reported baseline only."""
+    import oracle
+
+    deltas, scores, fm, hd, hp = inputs
+    anchors = oracle.generate_anchors(hyper)
+
+    def one_batch():
+        rois = oracle.roi_bbox(deltas, scores, anchors, hyper["variances"], cfg["K"], cfg["R"], hyper["nms_iou_threshold"])
+        oracle.roi_pooling(fm, rois, hyper["pooling_size"])
+        oracle.decoder(rois, hd, hp, hyper["variances"], cfg["L"])
+
+    out = {}
+    for label, threads in (("1", 1), ("all", max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1)))):
+        oracle.set_threads(threads)
+        one_batch()  # warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one_batch()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= min_seconds / 2 or n >= 200:
+                break
+        out[label] = (threads, n, cfg["B"] * n / dt)
+    threads, n, ips = out["all"]
+    return {
+        "value": round(ips, 2), "unit": "images/s", "cores": threads, "kind": "port",
+        "sample": f"{n} batches of {cfg['B']} images (config 2), oracle/ C restatement, OpenMP over images/boxes",
+        "value_1thread": round(out["1"][2], 2),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    import tf_faster_rcnn_amd as pkg
+
+    cfg = dict(CFG)
+    hyper = pkg.train_utils.get_hyper_params(cfg["backbone"])
+    hyper["total_labels"] = cfg["L"]
+    inputs = make_inputs(cfg, seed=rank)
+    deltas, scores, fm, hd, hp = (torch.as_tensor(a).to(device) for a in inputs)
+    anchors = pkg.bbox_utils.generate_anchors(hyper)
+    roi_bbox = pkg.faster_rcnn.RoIBBox(anchors, "inference", hyper, name="roi_bboxes")
+    roi_pool = pkg.faster_rcnn.RoIPooling(hyper, name="roi_pooling")
+    decoder = pkg.faster_rcnn.Decoder(hyper["variances"], cfg["L"], name="faster_rcnn_decoder")
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        rois = roi_bbox([deltas, scores])
+        if i is not None:
+            ev0[i].record()  # on the stream the kernel is launched on (torch's current stream)
+        pooled = roi_pool([fm, rois])
+        if i is not None:
+            ev1[i].record()
+        dets = decoder([rois, hd, hp])
+        return pooled, dets
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    crop_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if args.steps else float("nan")
+
+    if rank == 0:
+        images = cfg["B"] * world * args.steps
+        value = images / elapsed
+        crop_bytes = crop_bytes_per_image(cfg) * cfg["B"]
+        achieved = crop_bytes / (crop_ms * 1e-3) / 1e9
+        result = {
+            "metric": "images/sec through RPN decode+NMS+RoIPool+class NMS (bs16, 500^2); HBM GB/s",
+            "value": round(value, 1),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: mobilenet_v2 RoI path, batch 16 per GPU, 500x500, 9216 anchors/img, "
+                                   "pre_nms_topn 6000, post_nms 300, 7x7 crop_and_resize of 32x32x576, 21-label Decoder NMS",
+                       "global_batch": cfg["B"] * world, "parallelism": f"dp{world} over images, no collectives"},
+            "roofline": {"kernel": "crop_resize_kernel<4>", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, inputs, hyper)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,11 +115,14 @@ def get_bboxes_from_deltas(anchors, deltas, variances: Optional[Sequence[float]]
     """anchors (N,4) or same shape as deltas; deltas (..., N, 4)."""
     anchors, deltas = _f32(anchors), _f32(deltas)
     shape = deltas.shape
-    batched = int(anchors.shape == deltas.shape and deltas.ndim > 2) or int(anchors.ndim == deltas.ndim and anchors.ndim > 2)
     N = shape[-2]
     B = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
-    if anchors.ndim == 2 and deltas.ndim == 2:
+    if anchors.ndim == 2:
+        assert anchors.shape[0] == N
         batched = 0
+    else:
+        assert anchors.shape == deltas.shape
+        batched = 1
     out = np.empty(shape, dtype=np.float32)
     var = None if variances is None else _f32(variances)
     lib().orc_decode(_p(anchors, _f32p), ctypes.c_int(batched), _p(deltas, _f32p), _p(var, _f32p),

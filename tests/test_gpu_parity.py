@@ -1,0 +1,380 @@
+"""GPU parity: every HIP entry point (through the C ABI) against the CPU oracle on the same inputs.
+
+Bar (north_star): index sets and integer outputs bit-exact; fp32 boxes / IoUs / pooled features are
+compared bit-exactly too (the kernels and the oracle evaluate the same separately-rounded fp32
+operations), which is stricter than the 1e-5 relative tolerance the north_star allows -- where a test
+falls back to the tolerance it says so.
+"""
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # north_star tolerance for boxes / IoUs / pooled features
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import tf_faster_rcnn_amd as p
+    return p
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+def assert_bits(actual, expected, what=""):
+    a = actual.detach().cpu().numpy() if hasattr(actual, "detach") else np.asarray(actual)
+    e = np.asarray(expected)
+    assert a.shape == e.shape, f"{what}: shape {a.shape} vs {e.shape}"
+    if a.dtype.kind == "f":
+        same = (a.view(np.uint32) == e.astype(np.float32).view(np.uint32)) | (np.isnan(a) & np.isnan(e))
+        # +0 / -0 are the same value; accept them as equal
+        same |= (a == e)
+    else:
+        same = a == e
+    if not same.all():
+        bad = np.argwhere(~same)
+        i = tuple(bad[0])
+        raise AssertionError(f"{what}: {len(bad)} of {a.size} elements differ; first at {i}: got {a[i]!r} want {e[i]!r}")
+
+
+# ------------------------------------------------------------------------------------------------
+# anchors / codec
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("backbone,over", [("mobilenet_v2", {}), ("vgg16", {}),
+                                           ("mobilenet_v2", dict(img_size=1000, feature_map_shape=63))])
+def test_generate_anchors(pkg, backbone, over):
+    hp = pkg.train_utils.get_hyper_params(backbone, **over)
+    got = pkg.bbox_utils.generate_anchors(hp)
+    want = oracle.generate_anchors(hp)
+    assert_bits(pkg.bbox_utils.generate_base_anchors(hp), oracle.generate_base_anchors(hp), "base anchors")
+    assert_bits(got, want, "anchors")
+
+
+def test_exp_log_restatement_bits(pkg):
+    """The device Cephes exp/log restatements agree bit for bit with the oracle's, via decode/encode."""
+    rng = np.random.default_rng(7)
+    n = 20000
+    d = np.zeros((1, n, 4), np.float32)
+    d[0, :, 2] = rng.uniform(-20, 20, n)
+    d[0, :, 3] = rng.normal(0, 3, n)
+    d[0, :5, 2] = [0.0, 88.5, -88.5, 100.0, -100.0]
+    a = np.tile(np.array([[0.0, 0.0, 1.0, 1.0]], np.float32), (n, 1))
+    got = pkg.bbox_utils.get_bboxes_from_deltas(dev(a), dev(d))
+    assert_bits(got, oracle.get_bboxes_from_deltas(a, d), "decode(exp)")
+    # log through encode: gt sizes over many magnitudes
+    g = np.zeros((1, n, 4), np.float32)
+    g[0, :, 2] = np.exp(rng.uniform(-30, 3, n)).astype(np.float32)
+    g[0, :, 3] = rng.uniform(1e-6, 4, n).astype(np.float32)
+    got = pkg.bbox_utils.get_deltas_from_bboxes(dev(a), dev(g))
+    assert_bits(got, oracle.get_deltas_from_bboxes(a, g), "encode(log)")
+
+
+@pytest.mark.parametrize("B,G", [(2, 8), (16, 32)])
+def test_decode_rpn(pkg, B, G):
+    hp = synth.hyper_params(feature_map_shape=G)
+    anchors = oracle.generate_anchors(hp)
+    deltas, _ = synth.rpn_outputs(0, B, G)
+    deltas = deltas.reshape(B, -1, 4)
+    got = pkg.bbox_utils.get_bboxes_from_deltas(dev(anchors), dev(deltas), variances=hp["variances"])
+    assert_bits(got, oracle.get_bboxes_from_deltas(anchors, deltas, hp["variances"]), "decode")
+    # plain function, caller-side variance multiply like the reference (models/faster_rcnn.py:149)
+    scaled = (deltas * np.asarray(hp["variances"], np.float32)).astype(np.float32)
+    got = pkg.bbox_utils.get_bboxes_from_deltas(dev(anchors), dev(scaled))
+    assert_bits(got, oracle.get_bboxes_from_deltas(anchors, scaled), "decode pre-scaled")
+
+
+def test_decode_same_shape_and_zero_deltas(pkg):
+    rng = np.random.default_rng(1)
+    rois = rng.random((2, 5, 3, 4)).astype(np.float32)
+    d = rng.normal(0, 0.3, (2, 5, 3, 4)).astype(np.float32)
+    got = pkg.bbox_utils.get_bboxes_from_deltas(dev(rois), dev(d))
+    want = oracle.get_bboxes_from_deltas(rois.reshape(-1, 4), d.reshape(1, -1, 4)).reshape(d.shape)
+    assert_bits(got, want, "decode same-shape")
+    # exp(0) == 1 exactly: zero deltas give back the anchor up to the centre round trip
+    a = np.array([[0.25, 0.25, 0.75, 0.5]], np.float32)
+    got = pkg.bbox_utils.get_bboxes_from_deltas(dev(a), dev(np.zeros((1, 1, 4), np.float32))).cpu().numpy()
+    np.testing.assert_array_equal(got[0], a)
+
+
+def test_encode(pkg):
+    hp = synth.hyper_params(feature_map_shape=8)
+    anchors = oracle.generate_anchors(hp)
+    rng = np.random.default_rng(3)
+    gt = rng.random((3, anchors.shape[0], 4)).astype(np.float32)
+    gt[..., 2:] += gt[..., :2]
+    gt[0, :50] = 0.0  # zero-size gt -> zero deltas
+    got = pkg.bbox_utils.get_deltas_from_bboxes(dev(anchors), dev(gt), variances=hp["variances"])
+    assert_bits(got, oracle.get_deltas_from_bboxes(anchors, gt, hp["variances"]), "encode")
+    # zero-size bbox dims -> 1e-3
+    bb = np.array([[0.5, 0.5, 0.5, 0.5]], np.float32)
+    g1 = np.array([[[0.4, 0.4, 0.6, 0.7]]], np.float32)
+    assert_bits(pkg.bbox_utils.get_deltas_from_bboxes(dev(bb), dev(g1)), oracle.get_deltas_from_bboxes(bb, g1), "encode eps")
+
+
+# ------------------------------------------------------------------------------------------------
+# IoU map
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,G,M", [(2, 8, 4), (3, 8, 7), (8, 32, 100), (1, 4, 1)])
+def test_iou_map(pkg, B, G, M):
+    hp = synth.hyper_params(feature_map_shape=G)
+    anchors = oracle.generate_anchors(hp)
+    gt, _ = synth.gt_boxes(0, B, M)
+    assert_bits(pkg.bbox_utils.generate_iou_map(dev(anchors), dev(gt)), oracle.generate_iou_map(anchors, gt), "iou_map")
+
+
+def test_iou_map_batched_and_nan(pkg):
+    rng = np.random.default_rng(5)
+    bb = rng.random((2, 33, 4)).astype(np.float32)
+    bb[..., 2:] += bb[..., :2]
+    gt = rng.random((2, 8, 4)).astype(np.float32)
+    gt[..., 2:] += gt[..., :2]
+    bb[0, 0] = 0.0
+    gt[0, 0] = 0.0  # 0/0 -> NaN, like the reference (no epsilon)
+    got = pkg.bbox_utils.generate_iou_map(dev(bb), dev(gt))
+    want = oracle.generate_iou_map(bb, gt)
+    assert np.isnan(want[0, 0, 0])
+    assert_bits(got, want, "iou_map batched")
+
+
+# ------------------------------------------------------------------------------------------------
+# top-k
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,K", [(2, 576, 64), (3, 1000, 1000), (16, 9216, 6000), (2, 35721, 12000), (1, 70000, 300), (2, 100, 1)])
+def test_top_k(pkg, B, N, K):
+    rng = np.random.default_rng(N + K)
+    s = rng.random((B, N)).astype(np.float32)
+    vals, idx = pkg.bbox_utils.top_k(dev(s), K)
+    wv, wi = oracle.top_k(s, K)
+    assert_bits(idx, wi, "top_k indices")
+    assert_bits(vals, wv, "top_k values")
+
+
+def test_top_k_ties_and_errors(pkg):
+    rng = np.random.default_rng(11)
+    s = rng.integers(0, 8, size=(4, 3000)).astype(np.float32) / 8.0  # heavy ties -> ascending index
+    s[0, :10] = [0.0, -0.0, 0.0, -0.0, 1.0, 1.0, -1.0, -1.0, 0.5, 0.5]
+    vals, idx = pkg.bbox_utils.top_k(dev(s), 2000)
+    wv, wi = oracle.top_k(s, 2000)
+    assert_bits(idx, wi, "top_k ties idx")
+    # ties in a segment that needs the radix select (n > LDS capacity)
+    s2 = rng.integers(0, 50, size=(2, 40000)).astype(np.float32)
+    _, idx2 = pkg.bbox_utils.top_k(dev(s2), 5000)
+    _, wi2 = oracle.top_k(s2, 5000)
+    assert_bits(idx2, wi2, "top_k select ties idx")
+    with pytest.raises(ValueError):
+        pkg.bbox_utils.top_k(dev(s), 3001)
+
+
+# ------------------------------------------------------------------------------------------------
+# NMS
+# ------------------------------------------------------------------------------------------------
+def _rand_boxes(rng, shape, spread=0.25):
+    c = rng.random(shape + (2,))
+    hw = rng.uniform(0.05, spread, shape + (2,))
+    return np.concatenate([c - hw, c + hw], -1).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,n,q,c,mpc,mt,iou,thr", [
+    (2, 64, 1, 1, 16, 16, 0.7, float("-inf")),
+    (2, 300, 5, 5, 20, 30, 0.5, 0.5),
+    (3, 300, 1, 4, 200, 200, 0.5, 0.3),
+    (2, 1000, 1, 1, 1000, 1000, 0.3, float("-inf")),  # dense suppression, several chunks, no early exit
+    (1, 700, 3, 3, 50, 40, 0.6, 0.2),
+])
+def test_combined_nms(pkg, B, n, q, c, mpc, mt, iou, thr):
+    rng = np.random.default_rng(n * 7 + c)
+    boxes = _rand_boxes(rng, (B, n, q))
+    boxes[0, : n // 4] = boxes[0, n // 4: 2 * (n // 4)]  # exact duplicates (IoU 1)
+    scores = rng.random((B, n, c)).astype(np.float32)
+    got = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(scores), max_output_size_per_class=mpc, max_total_size=mt,
+                                            iou_threshold=iou, score_threshold=thr)
+    want = oracle.combined_non_max_suppression(boxes, scores, mpc, mt, iou, thr)
+    for g, w, name in zip(got, want, ("boxes", "scores", "classes", "valid")):
+        assert_bits(g, w, f"nms {name}")
+
+
+def test_nms_known_answers(pkg):
+    # three boxes: b1 overlaps b0 with IoU just above 0.7, b2 is disjoint
+    boxes = np.array([[[[0.0, 0.0, 1.0, 1.0]], [[0.0, 0.0, 1.0, 0.72]], [[2.0, 2.0, 3.0, 3.0]]]], np.float32)
+    scores = np.array([[[0.9], [0.8], [0.7]]], np.float32)
+    b, s, c, v = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(scores), max_output_size_per_class=3, max_total_size=3,
+                                                    iou_threshold=0.7)
+    assert int(v[0]) == 2
+    np.testing.assert_array_equal(s.cpu().numpy()[0], np.array([0.9, 0.7, 0.0], np.float32))
+    np.testing.assert_array_equal(b.cpu().numpy()[0, 1], np.array([1, 1, 1, 1], np.float32))  # clipped to [0,1]
+    # IoU exactly equal to the threshold must NOT suppress (strict >): IoU(b0, half box) == 0.5
+    boxes = np.array([[[[0.0, 0.0, 1.0, 1.0]], [[0.0, 0.0, 1.0, 0.5]]]], np.float32)
+    scores = np.array([[[0.9], [0.8]]], np.float32)
+    _, _, _, v = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(scores), max_output_size_per_class=2, max_total_size=2,
+                                                    iou_threshold=0.5)
+    assert int(v[0]) == 2
+    # equal scores: lower index first (this build's documented tie rule)
+    boxes = np.array([[[[0.0, 0.0, 0.5, 0.5]], [[0.5, 0.5, 1.0, 1.0]]]], np.float32)
+    scores = np.array([[[0.6], [0.6]]], np.float32)
+    b, _, _, _ = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(scores), max_output_size_per_class=2, max_total_size=2)
+    np.testing.assert_array_equal(b.cpu().numpy()[0], boxes[0, :, 0])
+    # zero-area and inverted boxes: area <= 0 -> IoU 0 -> never suppressed
+    boxes = np.array([[[[0.2, 0.2, 0.2, 0.9]], [[0.2, 0.2, 0.2, 0.9]], [[0.9, 0.9, 0.1, 0.1]], [[0.1, 0.1, 0.9, 0.9]]]], np.float32)
+    scores = np.array([[[0.9], [0.8], [0.7], [0.6]]], np.float32)
+    got = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(scores), max_output_size_per_class=4, max_total_size=4)
+    want = oracle.combined_non_max_suppression(boxes, scores, 4, 4)
+    for g, w in zip(got, want):
+        assert_bits(g, w, "nms degenerate")
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+def _roi_bbox_case(pkg, seed, B, G, K, R, mode="inference", thr=0.7, unique=True):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=K, nms_iou_threshold=thr)
+    hp["train_nms_topn" if mode == "training" else "test_nms_topn"] = R
+    anchors = oracle.generate_anchors(hp)
+    deltas, scores = synth.rpn_outputs(seed, B, G, unique_scores=unique)
+    layer = pkg.faster_rcnn.RoIBBox(dev(anchors), mode, hp, name="roi_bboxes")
+    got = layer([dev(deltas), dev(scores)])
+    want = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, thr)
+    return got, want
+
+
+@pytest.mark.parametrize("B,G,K,R,thr", [(2, 8, 64, 16, 0.7), (2, 16, 2304, 300, 0.7), (2, 16, 2000, 2000, 0.3),
+                                         (3, 8, 576, 600, 0.7)])
+def test_roi_bbox_small(pkg, B, G, K, R, thr):
+    got, want = _roi_bbox_case(pkg, 0, B, G, K, R, thr=thr)
+    assert_bits(got, want, "RoIBBox")
+
+
+def test_roi_bbox_config2(pkg):
+    """BASELINE config 2: mobilenet_v2, B=16, N=9216, K=6000, R=300."""
+    got, want = _roi_bbox_case(pkg, 1, 16, 32, 6000, 300)
+    assert_bits(got, want, "RoIBBox cfg2")
+
+
+def test_roi_bbox_train_mode_and_ties(pkg):
+    got, want = _roi_bbox_case(pkg, 2, 4, 31, 6000, 2000, mode="training")
+    assert_bits(got, want, "RoIBBox cfg3-like (vgg16 grid, R=2000)")
+    got, want = _roi_bbox_case(pkg, 3, 2, 16, 1000, 100, unique=False, thr=0.5)
+    assert_bits(got, want, "RoIBBox non-unique scores")
+
+
+def test_roi_bbox_stress_shape(pkg):
+    """BASELINE config 5 shape: G=63 (35721 anchors), pre_nms_topn 12000 -> radix select path."""
+    got, want = _roi_bbox_case(pkg, 4, 2, 63, 12000, 300)
+    assert_bits(got, want, "RoIBBox cfg5")
+
+
+def test_roi_bbox_k_gt_n_raises(pkg):
+    with pytest.raises(ValueError):
+        _roi_bbox_case(pkg, 0, 1, 4, 1000, 10)
+
+
+@pytest.mark.parametrize("B,G,C,R", [(2, 8, 8, 16), (2, 5, 6, 7), (16, 32, 576, 300), (2, 31, 512, 64)])
+def test_roi_pooling(pkg, B, G, C, R):
+    hp = synth.hyper_params()
+    fm = synth.feature_map(0, B, G, C)
+    rng = np.random.default_rng(9)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    rois[:, -2:] = 0.0                     # zero-padded RoIs sample pixel (0,0)
+    rois[0, 0] = [0.0, 0.0, 1.0, 1.0]      # touches the border exactly
+    rois[0, 1] = [-0.2, 0.3, 1.3, 0.6]     # extrapolated rows
+    rois[0, 2] = [0.3, -0.5, 0.6, 1.5]     # extrapolated columns
+    layer = pkg.faster_rcnn.RoIPooling(hp, name="roi_pooling")
+    got = layer([dev(fm), dev(rois)])
+    want = oracle.roi_pooling(fm, rois, hp["pooling_size"])
+    assert_bits(got, want, "RoIPooling")
+
+
+def test_crop_and_resize_generic(pkg):
+    rng = np.random.default_rng(13)
+    img = rng.normal(size=(3, 6, 9, 5)).astype(np.float32)
+    boxes = np.sort(rng.random((11, 2, 2)).astype(np.float32), axis=1).reshape(11, 4)
+    ind = rng.integers(0, 3, 11).astype(np.int32)
+    for crop in [(7, 7), (1, 1), (1, 4), (3, 1), (20, 17)]:
+        got = pkg.bbox_utils.crop_and_resize(dev(img), dev(boxes), dev(ind), crop, extrapolation_value=-1.5)
+        assert_bits(got, oracle.crop_and_resize(img, boxes, ind, crop, -1.5), f"crop {crop}")
+    # known answer: 2x2 map, box (0,0,1,1) -> linear ramp i/6
+    ramp = np.array([[[[0.0], [1.0]], [[0.0], [1.0]]]], np.float32)
+    got = pkg.bbox_utils.crop_and_resize(dev(ramp), dev(np.array([[0, 0, 1, 1]], np.float32)), dev(np.array([0], np.int32)), (7, 7))
+    np.testing.assert_allclose(got.cpu().numpy()[0, 3, :, 0], np.arange(7) / 6.0, rtol=RTOL)
+    with pytest.raises(ValueError):
+        pkg.bbox_utils.crop_and_resize(dev(img), dev(boxes), dev(np.full(11, 3, np.int32)), (7, 7))
+
+
+@pytest.mark.parametrize("B,R,L", [(2, 16, 5), (16, 300, 21), (3, 300, 21)])
+def test_decoder(pkg, B, R, L):
+    hp = synth.hyper_params()
+    rng = np.random.default_rng(R + L)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    rois[:, -3:] = 0.0
+    deltas, probs = synth.head_outputs(0, B, R, L)
+    layer = pkg.faster_rcnn.Decoder(hp["variances"], L, name="faster_rcnn_decoder")
+    got = layer([dev(rois), dev(deltas), dev(probs)])
+    want = oracle.decoder(rois, deltas, probs, hp["variances"], L)
+    for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
+        assert_bits(g, w, f"Decoder {name}")
+
+
+def test_decoder_unnormalised_scores(pkg):
+    """Un-normalised scores: several classes (incl. class 0) above threshold per RoI, cross-class ties."""
+    hp = synth.hyper_params()
+    B, R, L = 2, 120, 6
+    rng = np.random.default_rng(21)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    deltas = rng.normal(0, 0.5, (B, R, L * 4)).astype(np.float32)
+    probs = (rng.integers(0, 10, (B, R, L)) / 10.0).astype(np.float32)
+    layer = pkg.faster_rcnn.Decoder(hp["variances"], L, max_total_size=50, score_threshold=0.35)
+    got = layer([dev(rois), dev(deltas), dev(probs)])
+    want = oracle.decoder(rois, deltas, probs, hp["variances"], L, 50, 0.35)
+    for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
+        assert_bits(g, w, f"Decoder un-normalised {name}")
+
+
+# ------------------------------------------------------------------------------------------------
+# RPN targets
+# ------------------------------------------------------------------------------------------------
+def test_select_mask(pkg):
+    rng = np.random.default_rng(17)
+    B, N = 5, 3000
+    mask = rng.random((B, N)) < 0.3
+    mask[1] = False
+    mask[2] = True
+    rnd = rng.integers(1, 1280, (B, N), dtype=np.int32)
+    rnd[3] = rng.integers(-5, 5, N)  # out-of-contract integers (<= 0) still follow the argsort definition
+    for sel in ([128], [0, 50, 4000, 7, 128]):
+        got = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(np.asarray(sel, np.int32)), random_mask=dev(rnd))
+        want = oracle.randomly_select_xyz_mask(mask, sel, rnd)
+        assert_bits(got, want, f"select_mask {sel}")
+    # without injected integers: at most `select` kept, all inside the mask
+    got = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(np.asarray([128], np.int32))).cpu().numpy()
+    assert (got <= mask).all() and (got.sum(1) == np.minimum(mask.sum(1), 128)).all()
+
+
+@pytest.mark.parametrize("B,G,M", [(2, 8, 4), (8, 32, 100), (3, 31, 17)])
+def test_rpn_targets(pkg, B, G, M):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G)
+    anchors = oracle.generate_anchors(hp)
+    N = anchors.shape[0]
+    gt, labels = synth.gt_boxes(1, B, M)
+    rp, rn = synth.sampling_ints(1, B, N)
+    got_d, got_l = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp,
+                                                                random_masks=(dev(rp), dev(rn)))
+    want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
+    assert_bits(got_l, want_l, "rpn labels")
+    assert_bits(got_d, want_d, "rpn deltas")
+    # in-kernel draw: structural properties
+    d2, l2 = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp, seed=5)
+    l2 = l2.cpu().numpy().reshape(B, -1)
+    assert ((l2 == 1).sum(1) <= hp["total_pos_bboxes"]).all()
+    assert ((l2 == 1).sum(1) + (l2 == 0).sum(1) <= hp["total_pos_bboxes"] + hp["total_neg_bboxes"]).all()
+    assert set(np.unique(l2)) <= {-1.0, 0.0, 1.0}
+    nz = np.abs(d2.cpu().numpy()).sum(-1).reshape(B, -1) != 0
+    assert (nz <= (l2 == 1)).all()
