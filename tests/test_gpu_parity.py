@@ -228,6 +228,26 @@ def test_nms_known_answers(pkg):
     want = oracle.combined_non_max_suppression(boxes, scores, 4, 4)
     for g, w in zip(got, want):
         assert_bits(g, w, "nms degenerate")
+    # non-finite coordinates take the reference formulation (std::min/std::max NaN behaviour and all)
+    rng = np.random.default_rng(33)
+    boxes = _rand_boxes(rng, (2, 200, 1))
+    boxes[0, 5, 0] = [np.nan, 0.1, 0.5, 0.6]
+    boxes[0, 9, 0] = [0.1, 0.1, np.inf, 0.6]
+    boxes[1, 3, 0] = [-np.inf, -np.inf, np.inf, np.inf]
+    boxes[1, 7, 0] = [0.2, np.nan, np.nan, 0.3]
+    scores = rng.random((2, 200, 1)).astype(np.float32)
+    got = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(scores), max_output_size_per_class=200, max_total_size=200,
+                                            iou_threshold=0.3)
+    want = oracle.combined_non_max_suppression(boxes, scores, 200, 200, 0.3)
+    for g, w in zip(got, want):
+        assert_bits(g, w, "nms non-finite")
+    # thresholds at the edges of the exact compare: 0, negative, > 1
+    for thr in (0.0, -0.5, 1.5, 1.0):
+        got = pkg.bbox_utils.non_max_suppression(dev(boxes[:, 20:]), dev(scores[:, 20:]), max_output_size_per_class=50,
+                                                max_total_size=50, iou_threshold=thr)
+        want = oracle.combined_non_max_suppression(boxes[:, 20:], scores[:, 20:], 50, 50, thr)
+        for g, w in zip(got, want):
+            assert_bits(g, w, f"nms iou_threshold={thr}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -269,6 +289,28 @@ def test_roi_bbox_stress_shape(pkg):
     """BASELINE config 5 shape: G=63 (35721 anchors), pre_nms_topn 12000 -> radix select path."""
     got, want = _roi_bbox_case(pkg, 4, 2, 63, 12000, 300)
     assert_bits(got, want, "RoIBBox cfg5")
+
+
+def test_roi_bbox_unfused_path(pkg, monkeypatch):
+    """The generic sort -> NMS pipeline behind frcnn_roi_bbox (taken when the fused kernel's LDS budget is exceeded)."""
+    monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+    got, want = _roi_bbox_case(pkg, 5, 4, 32, 6000, 300)
+    assert_bits(got, want, "RoIBBox unfused cfg2")
+    got, want = _roi_bbox_case(pkg, 6, 2, 63, 12000, 300)
+    assert_bits(got, want, "RoIBBox unfused cfg5")
+
+
+def test_roi_bbox_dense_suppression(pkg):
+    """Heavily overlapping proposals (tiny deltas, IoU threshold 0.1): several slices and chunks are consumed."""
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=16, pre_nms_topn=2304, test_nms_topn=300, nms_iou_threshold=0.1)
+    anchors = oracle.generate_anchors(hp)
+    deltas, scores = synth.rpn_outputs(8, 3, 16)
+    deltas = (deltas * 0.05).astype(np.float32)
+    got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+    want, _, valid = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], 2304, 300, 0.1, return_all=True)
+    assert (valid < 300).all(), "case should exhaust the candidates"
+    assert_bits(got, want, "RoIBBox dense")
 
 
 def test_roi_bbox_k_gt_n_raises(pkg):

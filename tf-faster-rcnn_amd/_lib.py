@@ -14,7 +14,8 @@ from typing import Any, Dict, Optional, Sequence, Tuple
 import torch  # must be imported before the library so both share one HIP runtime (libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfrcnn_hip.so")
+# FRCNN_HIP_LIB overrides the path (diagnostic builds only); the default is the in-tree library.
+LIB_PATH = os.environ.get("FRCNN_HIP_LIB") or os.path.join(_HERE, "libfrcnn_hip.so")
 
 FRCNN_OK = 0
 FRCNN_EINVAL = -1

@@ -25,6 +25,23 @@ int check_launch(const char *what) { return check_hip(hipGetLastError(), what); 
 
 }  // namespace frcnn
 
+#ifdef FRCNN_STAMPS
+namespace frcnn {
+__device__ long long g_stamps[256];
+__device__ int g_nstamps;
+}
+extern "C" int frcnn_debug_stamps(long long *host_out, int reset) {
+  int n = 0;
+  hipMemcpyFromSymbol(&n, HIP_SYMBOL(frcnn::g_nstamps), sizeof(int));
+  hipMemcpyFromSymbol(host_out, HIP_SYMBOL(frcnn::g_stamps), sizeof(long long) * 256);
+  if (reset) {
+    int z = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(frcnn::g_nstamps), &z, sizeof(int));
+  }
+  return n;
+}
+#endif
+
 extern "C" {
 
 int frcnn_version(void) { return 100; /* 0.1.0 */ }

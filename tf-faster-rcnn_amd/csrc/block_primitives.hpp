@@ -1,0 +1,190 @@
+// block_primitives.hpp -- workgroup-cooperative building blocks (1024 threads = 16 waves of 64):
+// exclusive scan, wave-aggregated LDS histogram add, 4x8-bit radix SELECT and the stable LSD radix
+// SORT of 16-bit slot numbers.  Used by sort_select.hip, proposal.hip and rpn_targets.hip.
+//
+// All functions must be called by every thread of the block (they contain __syncthreads()).
+#pragma once
+
+#include "common.hpp"
+
+namespace frcnn {
+
+static const int kNT = 1024;
+static const int kNW = 16;
+
+// Exclusive scan of one int per thread; `total` is returned to every thread.  wsum: kNW ints of LDS.
+__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  __syncthreads();  // wsum may still be read from a previous call
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kNW; ++i) {
+    int s = wsum[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + inc - v;
+}
+
+// hist[bin] += 1 for every active lane with `valid`.  The two most frequent... rather: the bins of the first
+// two distinct pending lanes are added wave-aggregated (one LDS add of the lane count each); what is left
+// adds individually.  For the high-order digits of fp32 scores a wave sees one or two distinct bins, and 64
+// same-address LDS atomics (which the LDS serialises) collapse into one or two.
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool valid) {
+  bool pend = valid;
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const unsigned long long act = __ballot(pend);
+    if (act == 0ull) return;  // wave-uniform
+    const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(act));
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
+    const unsigned long long same = __ballot(pend && (bin == b0));
+    if (lane_id() == first) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
+    pend = pend && (bin != b0);
+  }
+  if (pend) atomicAdd(&hist[bin], 1u);
+}
+
+// Radix select over n elements.  keyf(i, key) -> bool valid (key: smaller = earlier).  Finds the key T
+// that the element of 1-based ascending rank `need` carries, and need_eq = how many elements equal to T
+// are inside the first `need` (to be taken in index order).  all = true when fewer than `need` valid
+// elements exist (then every valid element is inside).  hist: >= 256 uint32 of LDS, misc: >= 4 ints.
+template <class KeyF>
+__device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_t *hist, int *misc, uint32_t &T,
+                                             int &need_eq, bool &all) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __syncthreads();
+  if (tid == 0) misc[2] = 0;
+  uint32_t prefix = 0;
+  all = false;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const int n_up = (n + kNT - 1) / kNT * kNT;
+    for (int i = tid; i < n_up; i += kNT) {  // uniform trip count: hist_add uses wave ballots
+      uint32_t k = 0;
+      bool v = (i < n) && keyf(i, k);
+      v = v && (pass == 3 || (k >> (shift + 8)) == prefix);
+      hist_add(hist, (k >> shift) & 255u, v);
+    }
+    __syncthreads();
+    if (w == 0) {
+      const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const uint32_t s4 = h0 + h1 + h2 + h3;
+      uint32_t inc = s4;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += t;
+      }
+      const uint32_t exc = inc - s4;
+      const bool here = (exc < (uint32_t)need) && (inc >= (uint32_t)need);
+      const unsigned long long bal = __ballot(here);
+      if (bal == 0ull) {
+        if (lane == 0) misc[2] = 1;
+      } else if (here) {
+        uint32_t cum = exc;
+        int d = 4 * lane;
+        if (cum + h0 < (uint32_t)need) {
+          cum += h0;
+          ++d;
+          if (cum + h1 < (uint32_t)need) {
+            cum += h1;
+            ++d;
+            if (cum + h2 < (uint32_t)need) {
+              cum += h2;
+              ++d;
+            }
+          }
+        }
+        misc[0] = (int)((prefix << 8) | (uint32_t)d);
+        misc[1] = need - (int)cum;
+      }
+    }
+    __syncthreads();
+    if (misc[2]) {
+      all = true;
+      break;
+    }
+    prefix = (uint32_t)misc[0];
+    need = misc[1];
+    __syncthreads();  // misc is rewritten by the next pass
+  }
+  T = prefix;
+  need_eq = need;
+  __syncthreads();
+}
+
+// Stable least-significant-digit radix sort (4 passes of 8 bits) of V slot numbers by keys[slot].
+// perm[0..V) holds the initial order (normally 0..V-1) and, after the even number of passes, the sorted
+// order; perm[stride..stride+V) is the ping-pong scratch.  (The two halves are addressed through one base
+// pointer and an integer offset: selecting between two LDS pointers makes hipcc 7.2 emit an illegal
+// null-check on src_shared_base.)  hist: kNW*256 uint32 of LDS; wsum: kNW ints.  V <= 65536.
+__device__ __forceinline__ void block_sort_perm(const uint32_t *keys, uint16_t *perm, int stride, int V,
+                                                uint32_t *hist, int *wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nchunks = (V + 63) >> 6;
+  const int cpw = (nchunks + kNW - 1) / kNW;
+  const int c0 = w * cpw;
+  const int c1 = (c0 + cpw < nchunks) ? (c0 + cpw) : nchunks;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    const int src = (pass & 1) ? stride : 0;
+    const int dst = stride - src;
+    for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
+    __syncthreads();  // also publishes keys / permA on the first pass
+    for (int ch = c0; ch < c1; ++ch) {
+      const int p = (ch << 6) + lane;
+      const bool valid = p < V;
+      const uint32_t d = valid ? ((keys[perm[src + p]] >> shift) & 255u) : 0u;
+      hist_add(hist, d * kNW + w, valid);
+    }
+    __syncthreads();
+    {
+      const uint32_t a0 = hist[4 * tid], a1 = hist[4 * tid + 1], a2 = hist[4 * tid + 2], a3 = hist[4 * tid + 3];
+      int total;
+      const int ex = block_excl_scan((int)(a0 + a1 + a2 + a3), wsum, total);
+      hist[4 * tid] = (uint32_t)ex;
+      hist[4 * tid + 1] = (uint32_t)ex + a0;
+      hist[4 * tid + 2] = (uint32_t)ex + a0 + a1;
+      hist[4 * tid + 3] = (uint32_t)ex + a0 + a1 + a2;
+    }
+    __syncthreads();
+    for (int ch = c0; ch < c1; ++ch) {
+      const int p = (ch << 6) + lane;
+      const bool valid = p < V;
+      const uint32_t id = valid ? (uint32_t)perm[src + p] : 0u;
+      const uint32_t d = (keys[id] >> shift) & 255u;
+      unsigned long long peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool on = (d >> bit) & 1u;
+        const unsigned long long bm = __ballot(on);
+        peers &= on ? bm : ~bm;
+      }
+      if (valid) {
+        // relaxed atomics (not volatile: a volatile LDS access is lowered through a generic pointer by hipcc 7.2)
+        const uint32_t base = __hip_atomic_load(&hist[d * kNW + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const int r = __popcll(peers & lanemask_lt());
+        perm[dst + (int)base + r] = (uint16_t)id;
+        if (r == 0)
+          __hip_atomic_store(&hist[d * kNW + w], base + (uint32_t)__popcll(peers), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace frcnn

@@ -226,6 +226,22 @@ __device__ __forceinline__ bool nms_iou_gt(const NBox &i, const NBox &j, float t
   return iou > thr;
 }
 
+// ---- diagnostic stamps (only in builds with -DFRCNN_STAMPS; the shipped library has none) ---------
+#ifdef FRCNN_STAMPS
+extern __device__ long long g_stamps[256];
+extern __device__ int g_nstamps;
+#define FRCNN_STAMP(tag)                                                  \
+  do {                                                                    \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g_nstamps < 127) {         \
+      g_stamps[2 * g_nstamps] = ((long long)(tag) << 48) | ((long long)clock64() & 0xFFFFFFFFFFFFll); \
+      g_stamps[2 * g_nstamps + 1] = (long long)wall_clock64();            \
+      ++g_nstamps;                                                        \
+    }                                                                     \
+  } while (0)
+#else
+#define FRCNN_STAMP(tag) do { } while (0)
+#endif
+
 // ---- wave helpers (wave = 64 lanes on gfx950) ---------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ uint64_t lanemask_lt() {

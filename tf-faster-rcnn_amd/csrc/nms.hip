@@ -24,11 +24,12 @@
 // The IoU test is TF's IOUGreaterThanThreshold verbatim (corner-normalised boxes, area <= 0 never
 // overlaps, fp32 divide, strict '>'), evaluated on the UNCLIPPED boxes; clipping to [0,1] is applied
 // to the emitted boxes only (clip_boxes=True).
+#include <stdlib.h>
+
+#include "nms_core.hpp"
 #include "sort_select.hpp"
 
 namespace frcnn {
-
-static const int kChunk = 256;
 
 struct NmsParams {
   BoxSource box;
@@ -36,7 +37,7 @@ struct NmsParams {
   int c;           // classes (segments per image)
   int n;           // boxes per image
   int R;           // max kept per segment (= min(max_output_size_per_class, n))
-  float iou_thr;
+  IouThr iou;
   int use_thr;     // re-check score > score_thr when loading candidates (RoIBBox: top_k did not filter)
   float score_thr;
   const int *sorted_idx;  // (S, sorted_stride)
@@ -56,179 +57,31 @@ struct NmsParams {
   int *seg_count;    // (S)
 };
 
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-  uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-  uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
-  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// LDS carve (dynamic): kept list (5 floats + 1 int per entry, Rc entries), chunk (5 floats + 1 int
-// per entry, 256 entries), mask 256x4 u64, dead 4 u64, 2 ints.
-template <int NT>
+// LDS (dynamic): see NmsLds in nms_core.hpp.
+template <int NT, int CH>
 __global__ __launch_bounds__(NT) void nms_kernel(NmsParams p, int Rc) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned long long *mask = reinterpret_cast<unsigned long long *>(smem);  // [256*4]
-  unsigned long long *dead = mask + kChunk * 4;                             // [4]
-  float *c_ymin = reinterpret_cast<float *>(dead + 4);
-  float *c_xmin = c_ymin + kChunk;
-  float *c_ymax = c_xmin + kChunk;
-  float *c_xmax = c_ymax + kChunk;
-  float *c_area = c_xmax + kChunk;
-  int *c_idx = reinterpret_cast<int *>(c_area + kChunk);
-  int *s_nk = c_idx + kChunk;  // [4]
-  float *k_ymin = reinterpret_cast<float *>(s_nk + 4);
-  float *k_xmin = k_ymin + Rc;
-  float *k_ymax = k_xmin + Rc;
-  float *k_xmax = k_ymax + Rc;
-  float *k_area = k_xmax + Rc;
-  int *k_idx = reinterpret_cast<int *>(k_area + Rc);
+  const NmsLds<CH> L = carve_nms_lds<CH>(smem, Rc);
+  int *k_idx = L.k_idx;
 
   const int seg = blockIdx.x;
   const int b = seg / p.c;
   const int cls = seg - b * p.c;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  constexpr int NWV = NT / 64;
-  const float thr = p.iou_thr;
+  const int tid = threadIdx.x;
 
   int count = p.counts ? p.counts[seg] : p.n;
   if (count > p.n) count = p.n;
   const int R = p.R;
   const int *sidx = p.sorted_idx + (long long)seg * p.sorted_stride;
 
-  if (tid == 0) s_nk[0] = 0;
-  __syncthreads();
   int nk = 0;
-
-  for (int base = 0; base < count && nk < R; base += kChunk) {
-    const int nc = (count - base < kChunk) ? (count - base) : kChunk;
-    // ---- load the chunk ------------------------------------------------------------------------
-    if (tid < kChunk) {
-      NBox nb;
-      nb.ymin = nb.xmin = nb.ymax = nb.xmax = nb.area = 0.0f;
-      int ei = -1;
-      bool bad = false;
-      if (tid < nc) {
-        ei = sidx[base + tid];
-        nb = normalise_box(load_box(p.box, b, ei, cls));
-        if (p.use_thr) bad = !(load_score(p.score, b, ei, cls) > p.score_thr);
-      }
-      c_ymin[tid] = nb.ymin;
-      c_xmin[tid] = nb.xmin;
-      c_ymax[tid] = nb.ymax;
-      c_xmax[tid] = nb.xmax;
-      c_area[tid] = nb.area;
-      c_idx[tid] = ei;
-      // candidates that fail the score threshold start out dead
-      const unsigned long long badw = __ballot(bad);
-      if (lane == 0) dead[w] = badw;
-    }
-    __syncthreads();
-
-    // ---- a. chunk vs kept list ----------------------------------------------------------------
-    if (nk > 0) {
-      const int j = tid & (kChunk - 1);
-      const int slice = tid >> 8;
-      constexpr int NSL = NT >> 8;
-      NBox me;
-      me.ymin = c_ymin[j];
-      me.xmin = c_xmin[j];
-      me.ymax = c_ymax[j];
-      me.xmax = c_xmax[j];
-      me.area = c_area[j];
-      bool d = false;
-      for (int k = slice; k < nk; k += NSL) {
-        NBox kb;
-        kb.ymin = k_ymin[k];
-        kb.xmin = k_xmin[k];
-        kb.ymax = k_ymax[k];
-        kb.xmax = k_xmax[k];
-        kb.area = k_area[k];
-        d = d || nms_iou_gt(me, kb, thr);
-        if (__all(d)) break;
-      }
-      const unsigned long long word = __ballot(d && (j < nc));
-      if (lane == 0 && word != 0ull) atomicOr(&dead[j >> 6], word);
-    }
-
-    // ---- b. intra-chunk IoU tiles (upper triangle), 16 rows per work item -----------------------
-    for (int item = w; item < 40; item += NWV) {
-      const int tile = item >> 2;
-      const int quarter = item & 3;
-      const int rg = (tile >= 9) ? 3 : (tile >= 7) ? 2 : (tile >= 4) ? 1 : 0;
-      const int tstart = (rg == 0) ? 0 : (rg == 1) ? 4 : (rg == 2) ? 7 : 9;
-      const int cg = rg + (tile - tstart);
-      if (rg * 64 >= nc || cg * 64 >= nc) continue;  // wave-uniform
-      const int jcol = cg * 64 + lane;
-      NBox me;
-      me.ymin = c_ymin[jcol];
-      me.xmin = c_xmin[jcol];
-      me.ymax = c_ymax[jcol];
-      me.xmax = c_xmax[jcol];
-      me.area = c_area[jcol];
-#pragma unroll 4
-      for (int ii = 0; ii < 16; ++ii) {
-        const int irow = rg * 64 + quarter * 16 + ii;
-        NBox rb;
-        rb.ymin = c_ymin[irow];
-        rb.xmin = c_xmin[irow];
-        rb.ymax = c_ymax[irow];
-        rb.xmax = c_xmax[irow];
-        rb.area = c_area[irow];
-        const bool bit = (irow < jcol) && (jcol < nc) && nms_iou_gt(rb, me, thr);
-        const unsigned long long word = __ballot(bit);
-        if (lane == 0) mask[irow * 4 + cg] = word;
-      }
-    }
-    __syncthreads();
-
-    // ---- c. greedy resolve on wave 0 ------------------------------------------------------------
-    if (w == 0) {
-      unsigned long long rem[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) rem[g] = uniform64(dead[g]);
-      int cnt = nk;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int left = nc - g * 64;
-        if (left > 0 && cnt < R) {  // wave-uniform
-          unsigned long long row[4];
-#pragma unroll
-          for (int w2 = 0; w2 < 4; ++w2) row[w2] = (w2 >= g) ? mask[(g * 64 + lane) * 4 + w2] : 0ull;
-          const unsigned long long valid = (left >= 64) ? ~0ull : ((1ull << left) - 1ull);
-          unsigned long long alive = uniform64(~rem[g] & valid);
-          unsigned long long keptbits = 0ull;
-          while (alive != 0ull && cnt < R) {
-            const int i = (int)__builtin_ctzll(alive);
-            keptbits |= (1ull << i);
-            ++cnt;
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2)
-              if (w2 >= g) rem[w2] |= readlane64(row[w2], i);
-            alive &= ~(rem[g] | keptbits);
-          }
-          if ((keptbits >> lane) & 1ull) {
-            const int pos = nk + __popcll(keptbits & lanemask_lt());
-            const int j = g * 64 + lane;
-            k_ymin[pos] = c_ymin[j];
-            k_xmin[pos] = c_xmin[j];
-            k_ymax[pos] = c_ymax[j];
-            k_xmax[pos] = c_xmax[j];
-            k_area[pos] = c_area[j];
-            k_idx[pos] = c_idx[j];
-          }
-          nk += __popcll(keptbits);
-        }
-      }
-      if (lane == 0) s_nk[0] = nk;
-    }
-    __syncthreads();
-    nk = s_nk[0];
+  for (int base = 0; base < count && nk < R; base += CH) {
+    const int nc = (count - base < CH) ? (count - base) : CH;
+    nk = nms_chunk<NT, CH>(L, nc, nk, R, p.iou, [&](int j, float4 &box, int &ei, bool &bad) {
+      ei = sidx[base + j];
+      box = load_box(p.box, b, ei, cls);
+      if (p.use_thr) bad = !(load_score(p.score, b, ei, cls) > p.score_thr);
+    });
   }
 
   // ---- outputs -----------------------------------------------------------------------------------
@@ -280,9 +133,12 @@ struct MergeParams {
   int *out_valid;
 };
 
-__global__ __launch_bounds__(256) void merge_kernel(MergeParams p) {
+__global__ __launch_bounds__(256) void merge_kernel(MergeParams p, int staged) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int *cnt = reinterpret_cast<int *>(smem);  // [c]
+  const int cpad = (p.c + 3) & ~3;
+  int *cnt = reinterpret_cast<int *>(smem);        // [c]  kept per class
+  int *off = cnt + cpad;                           // [c]  exclusive prefix of cnt
+  float *lsc = reinterpret_cast<float *>(off + cpad);  // [c*R] when staged
   __shared__ int s_total;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int c = p.c, R = p.R, T = p.T;
@@ -293,24 +149,42 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeParams p) {
   __syncthreads();
   if (tid == 0) {
     int t = 0;
-    for (int k = 0; k < c; ++k) t += cnt[k];
+    for (int k = 0; k < c; ++k) {
+      off[k] = t;
+      t += cnt[k];
+    }
     s_total = t;
   }
+  const float *gsc = p.seg_score + (long long)b * c * R;
+  if (staged) {
+    // the kept lists are tiny: stage them in LDS so the binary searches do not chase global loads
+    for (int cls = 0; cls < c; ++cls)
+      for (int pos = tid; pos < cnt[cls]; pos += 256) lsc[cls * R + pos] = gsc[(long long)cls * R + pos];
+  }
   __syncthreads();
+  const float *sc = staged ? lsc : gsc;
   const int total = s_total;
   const int nvalid = total < T ? total : T;
-  const long long e_all = (long long)c * R;
-  for (long long e = tid; e < e_all; e += 256) {
-    const int cls = (int)(e / R);
-    const int pos = (int)(e - (long long)cls * R);
-    if (pos >= cnt[cls]) continue;
+  // one entry per thread: entry e of the concatenated lists -> (cls, pos) through the prefix table, so
+  // that all of an image's (few hundred) entries are ranked in parallel
+  for (int e = tid; e < total; e += 256) {
+    int cls = 0;
+    {
+      int lo = 0, hi = c - 1;  // last class with off[cls] <= e and cnt[cls] > 0
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      cls = lo;
+    }
+    const int pos = e - off[cls];
     const long long seg = (long long)b * c + cls;
-    const float s = p.seg_score[seg * R + pos];
+    const float s = sc[(long long)cls * R + pos];
     int rank = pos;
     for (int c2 = 0; c2 < c; ++c2) {
       const int n2 = cnt[c2];
       if (c2 == cls || n2 == 0) continue;
-      const float *l2 = p.seg_score + ((long long)b * c + c2) * R;
+      const float *l2 = sc + (long long)c2 * R;
       // number of entries of class c2 that come before (s, cls): s2 > s, or s2 == s and c2 < cls.
       int lo = 0, hi = n2;
       if (c2 < cls) {
@@ -349,12 +223,6 @@ __global__ __launch_bounds__(256) void merge_kernel(MergeParams p) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static const int kMaxKept = 6000;  // kept-list capacity in LDS (24 B per entry)
-
-static size_t nms_lds_bytes(int Rc) {
-  return (size_t)kChunk * 4 * 8 + 4 * 8 + (size_t)kChunk * 6 * 4 + 4 * 4 + (size_t)Rc * 6 * 4;
-}
-
 struct NmsWorkspace {
   int *sorted_idx;   // S * n
   int *counts;       // S
@@ -382,36 +250,35 @@ static NmsWorkspace carve_workspace(void *ws, long long S, int n, int R) {
   return w;
 }
 
-static int launch_nms(const NmsParams &p, long long S, hipStream_t stream) {
-  int Rc = (p.R + 7) & ~7;
-  if (Rc < 8) Rc = 8;
-  const size_t lds = nms_lds_bytes(Rc);
+template <int NT, int CH>
+static int launch_nms_t(const NmsParams &p, long long S, int Rc, hipStream_t stream) {
+  const size_t lds = nms_lds_bytes<CH>(Rc);
   if (p.R > kMaxKept || lds > 160 * 1024)
     return set_error(FRCNN_EUNSUPPORTED, "nms: %d boxes kept per class exceeds the in-LDS kept-list capacity %d", p.R, kMaxKept);
-  // Few candidates per segment (Decoder: <= R RoIs per class) -> 4 waves; RPN proposals -> 16 waves.
-  const bool small = p.n <= 1024;
-  dim3 grid((unsigned)S);
-  if (small) {
-    auto kern = nms_kernel<256>;
-    if (lds > 48 * 1024) {
-      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "nms: hipFuncSetAttribute");
-      if (rc) return rc;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p, Rc);
-  } else {
-    auto kern = nms_kernel<1024>;
-    if (lds > 48 * 1024) {
-      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "nms: hipFuncSetAttribute");
-      if (rc) return rc;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(1024), lds, stream, p, Rc);
+  auto kern = nms_kernel<NT, CH>;
+  if (lds > 48 * 1024) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "nms: hipFuncSetAttribute");
+    if (rc) return rc;
   }
+  hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(NT), lds, stream, p, Rc);
   return check_launch("nms");
 }
 
+static int launch_nms(const NmsParams &p, long long S, hipStream_t stream) {
+  int Rc = (p.R + 7) & ~7;
+  if (Rc < 8) Rc = 8;
+  // Few candidates per segment (Decoder: <= R RoIs per class) -> 4 waves, 64-wide chunks;
+  // many (RPN proposals) -> 16 waves, 256-wide chunks.
+  if (p.n <= 1024) return launch_nms_t<256, 64>(p, S, Rc, stream);
+  return launch_nms_t<1024, 256>(p, S, Rc, stream);
+}
+
 static int launch_merge(const MergeParams &m, int B, hipStream_t stream) {
-  const size_t lds = round_up((size_t)m.c * 4, 16);
-  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)B), dim3(256), lds, stream, m);
+  const size_t head = (size_t)((m.c + 3) & ~3) * 4 * 2;
+  const size_t full = head + (size_t)m.c * m.R * 4;
+  const int staged = full <= 60 * 1024;
+  const size_t lds = staged ? full : head;
+  hipLaunchKernelGGL(merge_kernel, dim3((unsigned)B), dim3(256), lds, stream, m, staged);
   return check_launch("nms merge");
 }
 
@@ -445,7 +312,7 @@ static int run_combined(const ScoreSource &score, const BoxSource &box, int B, i
   p.c = c;
   p.n = n;
   p.R = R;
-  p.iou_thr = iou_thr;
+  p.iou = make_iou_thr(iou_thr);
   p.use_thr = sort_thr ? 0 : 1;  // the sort did not filter: re-check when loading
   p.score_thr = score_thr;
   p.sorted_idx = w.sorted_idx;
@@ -481,6 +348,11 @@ static int run_combined(const ScoreSource &score, const BoxSource &box, int B, i
   }
   return rc;
 }
+
+// proposal.hip
+int launch_proposal(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
+                    int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
+                    int *out_valid, hipStream_t stream, bool *handled);
 
 }  // namespace frcnn
 
@@ -543,6 +415,18 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
   FRCNN_REQUIRE(aligned_to(deltas, 16) && aligned_to(anchors, 16) && aligned_to(out_boxes, 16),
                 "roi_bbox: box pointers must be 16-byte aligned");
   if (B == 0) return FRCNN_OK;
+  {
+    // One fused kernel per image (proposal.hip) whenever its LDS budget allows; FRCNN_ROI_BBOX_UNFUSED=1
+    // forces the generic sort -> NMS pipeline (used by the parity tests to cover both).
+    const char *force = getenv("FRCNN_ROI_BBOX_UNFUSED");
+    if (!(force && force[0] == '1')) {
+      bool handled = false;
+      const int Rn = R < K ? R : K;
+      int rc = launch_proposal(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
+                               out_scores, out_valid, (hipStream_t)stream, &handled);
+      if (rc || handled) return rc;
+    }
+  }
   ScoreSource ss;
   ss.scores = scores;
   ss.stride_b = N;

@@ -1,0 +1,242 @@
+// proposal.hip -- RoIBBox as ONE kernel: lazy top-K + decode + greedy NMS + clip, one workgroup per image.
+//
+// Replaces models/faster_rcnn.py:147-166 (tf.nn.top_k -> tf.gather -> combined_non_max_suppression).
+//
+// TF's NMS pops candidates from a priority queue and stops as soon as post_nms_topn boxes are kept, so
+// only a prefix of the 6000 pre-NMS candidates is ever looked at.  This kernel does the same, lazily:
+//   repeat until R boxes are kept or pre_nms_topn candidates are consumed
+//     1. radix SELECT (4x8-bit LDS histograms over the image's scores) of the next SLICE of the
+//        score order, i.e. ranks [consumed, consumed + S);
+//     2. stable compaction of that slice into LDS (index order) and a stable LSD radix SORT of it
+//        (ties: lower anchor index first, as tf.nn.top_k);
+//     3. greedy NMS over the slice in chunks of 256 (nms_core.hpp); candidate boxes are decoded on the
+//        fly from (anchor, delta * variance) -- the (B,N,4) decoded tensor, the (B,K) top-k indices and
+//        the gathered (B,K,4) boxes of the reference are never materialised;
+//   then the kept boxes are decoded once more, clipped to [0,1] and written with zero padding.
+// Everything between the RPN head outputs and the (B,R,4) RoIs stays inside one CU: no workspace, no
+// intermediate HBM traffic, one launch.  Latency/ALU bound (judged on images/s).
+#include <stdlib.h>
+
+#include "block_primitives.hpp"
+#include "nms_core.hpp"
+
+namespace frcnn {
+
+struct ProposalParams {
+  const float *deltas;   // (B,N,4)
+  const float *scores;   // (B,N)
+  const float *anchors;  // (N,4)
+  float v0, v1, v2, v3;
+  int N, K, R;
+  IouThr iou;
+  float score_thr;  // -inf: combined_non_max_suppression's default, strict '>'
+  float *out_boxes;   // (B,R,4)
+  float *out_scores;  // (B,R) or NULL
+  int *out_valid;     // (B) or NULL
+};
+
+template <int CH>
+static inline size_t proposal_lds_bytes(int Rc, int S) {
+  return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)kNW * 256 * 4 + 64 * 4;
+}
+
+// cache_keys: the image's N sort keys are held in LDS (after the other arrays) so that the radix-select
+// passes and the compaction read LDS instead of re-reading the scores through L2.
+template <int CH>
+__global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const NmsLds<CH> L = carve_nms_lds<CH>(smem, Rc);
+  unsigned char *q = smem + ((nms_lds_bytes<CH>(Rc) + 15) & ~(size_t)15);
+  uint32_t *keys = reinterpret_cast<uint32_t *>(q);            // [S]
+  uint32_t *orig = keys + S;                                   // [S]
+  uint32_t *hist = orig + S;                                   // [kNW*256]
+  int *wsum = reinterpret_cast<int *>(hist + kNW * 256);       // [32]
+  int *misc = wsum + 32;                                       // [32]
+  uint16_t *permA = reinterpret_cast<uint16_t *>(misc + 32);   // [S]
+  // permB = permA + S                                         // [S] (ping-pong half)
+  uint32_t *kcache = reinterpret_cast<uint32_t *>(permA + 2 * S);  // [N] when cache_keys
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = p.N, K = p.K, R = p.R;
+  const float *scores = p.scores + (long long)b * N;
+  const float4 *deltas = reinterpret_cast<const float4 *>(p.deltas) + (long long)b * N;
+  const float4 *anchors = reinterpret_cast<const float4 *>(p.anchors);
+
+  FRCNN_STAMP(0);
+  if (cache_keys) {
+    for (int i = tid; i < N; i += kNT) kcache[i] = ~f_order_key(scores[i]);
+    __syncthreads();
+  }
+  FRCNN_STAMP(1);
+  auto keyf = [&](int i, uint32_t &k) -> bool {
+    k = cache_keys ? kcache[i] : ~f_order_key(scores[i]);
+    return true;  // tf.nn.top_k ranks every element
+  };
+  auto box_of = [&](int i) -> float4 {
+    return decode_box(anchors[i], scale_deltas(deltas[i], p.v0, p.v1, p.v2, p.v3));
+  };
+
+  // consumed prefix of the score order = {key < T1} U {key == T1 and index-rank among equals < eq1}
+  uint32_t T1 = 0;
+  int eq1 = 0;
+  int consumed = 0, nk = 0;
+  bool exhausted = false;
+  const int E = (N + kNT - 1) / kNT;
+  const int i0 = tid * E;
+  const int i1 = (i0 + E < N) ? (i0 + E) : N;
+
+  while (nk < R && consumed < K && !exhausted) {
+    const int s_now = (K - consumed < S) ? (K - consumed) : S;
+    // ---- 1. key of rank consumed + s_now -----------------------------------------------------------
+    uint32_t T2;
+    int eq2;
+    bool all;
+    radix_select(keyf, N, consumed + s_now, hist, misc, T2, eq2, all);
+    FRCNN_STAMP(2);
+    if (all) {  // cannot happen while K <= N; kept for safety
+      T2 = 0xFFFFFFFFu;
+      eq2 = 0x7FFFFFFF;
+      exhausted = true;
+    }
+    // ---- 2. compact the slice (in2 and not in1) in index order --------------------------------------
+    int e1 = 0, e2 = 0;
+    for (int i = i0; i < i1; ++i) {
+      uint32_t k;
+      keyf(i, k);
+      e1 += (k == T1);
+      e2 += (k == T2);
+    }
+    int tot;
+    const int base1 = block_excl_scan(e1, wsum, tot);
+    const int base2 = block_excl_scan(e2, wsum, tot);
+    int cnt = 0;
+    {
+      int r1 = base1, r2 = base2;
+      for (int i = i0; i < i1; ++i) {
+        uint32_t k;
+        keyf(i, k);
+        const bool in1 = (k < T1) || (k == T1 && r1 < eq1);
+        const bool in2 = (k < T2) || (k == T2 && r2 < eq2);
+        r1 += (k == T1);
+        r2 += (k == T2);
+        cnt += (in2 && !in1);
+      }
+    }
+    int V;
+    int pos = block_excl_scan(cnt, wsum, V);
+    {
+      int r1 = base1, r2 = base2;
+      for (int i = i0; i < i1; ++i) {
+        uint32_t k;
+        keyf(i, k);
+        const bool in1 = (k < T1) || (k == T1 && r1 < eq1);
+        const bool in2 = (k < T2) || (k == T2 && r2 < eq2);
+        r1 += (k == T1);
+        r2 += (k == T2);
+        if (in2 && !in1 && pos < S) {
+          keys[pos] = k;
+          orig[pos] = (uint32_t)i;
+          permA[pos] = (uint16_t)pos;
+          ++pos;
+        }
+      }
+    }
+    FRCNN_STAMP(3);
+    if (V > S) V = S;  // defensive; V == s_now by construction
+    // ---- 3. order the slice ----------------------------------------------------------------------------
+    block_sort_perm(keys, permA, S, V, hist, wsum);
+    const uint16_t *perm = permA;
+    FRCNN_STAMP(4);
+    // ---- 4. greedy NMS over the slice ------------------------------------------------------------------
+    for (int cbase = 0; cbase < V && nk < R; cbase += CH) {
+      const int nc = (V - cbase < CH) ? (V - cbase) : CH;
+      nk = nms_chunk<1024, CH>(L, nc, nk, R, p.iou, [&](int j, float4 &box, int &ei, bool &bad) {
+        ei = (int)orig[perm[cbase + j]];
+        box = box_of(ei);
+        bad = !(scores[ei] > p.score_thr);
+      });
+    }
+    consumed += V;
+    T1 = T2;
+    eq1 = eq2;
+    if (V < s_now) exhausted = true;
+  }
+
+  // ---- outputs: (B,R,4) clipped, score-ordered, zero padded ----------------------------------------
+  for (int r = tid; r < R; r += kNT) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc = 0.0f;
+    if (r < nk) {
+      const int ei = L.k_idx[r];
+      o = box_of(ei);
+      o.x = clip01(o.x);
+      o.y = clip01(o.y);
+      o.z = clip01(o.z);
+      o.w = clip01(o.w);
+      sc = scores[ei];
+    }
+    *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * R + r) * 4) = o;
+    if (p.out_scores) p.out_scores[(long long)b * R + r] = sc;
+  }
+  if (tid == 0 && p.out_valid) p.out_valid[b] = nk;
+  FRCNN_STAMP(9);
+}
+
+template <int CH>
+static int launch_proposal_t(ProposalParams &p, int B, int Rc, int S, hipStream_t stream, bool *handled) {
+  size_t lds = proposal_lds_bytes<CH>(Rc, S);
+  if (lds > 160 * 1024) return FRCNN_OK;  // does not fit: the caller takes the unfused path
+  const int cache_keys = (lds + (size_t)p.N * 4 <= 160 * 1024) ? 1 : 0;
+  if (cache_keys) lds += (size_t)p.N * 4;
+  auto kern = proposal_kernel<CH>;
+  if (lds > 48 * 1024) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "roi_bbox: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kNT), lds, stream, p, Rc, S, cache_keys);
+  *handled = true;
+  return check_launch("roi_bbox (fused proposal kernel)");
+}
+
+// *handled stays false when the fused kernel cannot hold the problem in LDS; the caller then takes the
+// unfused sort -> NMS path.
+int launch_proposal(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
+                    int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
+                    int *out_valid, hipStream_t stream, bool *handled) {
+  *handled = false;
+  // R_out rows are written; at most R_nms = min(R_out, K) boxes can be kept.
+  if (R_nms != R_out) return FRCNN_OK;  // zero rows beyond K candidates: leave to the generic path
+  if (R_nms > kMaxKept) return FRCNN_OK;
+  int Rc = (R_nms + 7) & ~7;
+  if (Rc < 8) Rc = 8;
+  // slice: a few times the number of boxes wanted, in whole chunks, at most 4096
+  int S = ((2 * R_nms + 255) / 256) * 256;
+  if (S < 1024) S = 1024;
+  if (S > 4096) S = 4096;
+  ProposalParams p;
+  p.deltas = deltas;
+  p.scores = scores;
+  p.anchors = anchors;
+  p.v0 = variances[0];
+  p.v1 = variances[1];
+  p.v2 = variances[2];
+  p.v3 = variances[3];
+  p.N = N;
+  p.K = K;
+  p.R = R_nms;
+  p.iou = make_iou_thr(iou_thr);
+  p.score_thr = -__builtin_huge_valf();
+  p.out_boxes = out_boxes;
+  p.out_scores = out_scores;
+  p.out_valid = out_valid;
+  // chunk width: tuning knob (FRCNN_PROPOSAL_CHUNK = 64 | 128 | 256), default 128
+  int ch = 128;
+  if (const char *e = getenv("FRCNN_PROPOSAL_CHUNK")) ch = atoi(e);
+  if (ch == 64) return launch_proposal_t<64>(p, B, Rc, S, stream, handled);
+  if (ch == 256) return launch_proposal_t<256>(p, B, Rc, S, stream, handled);
+  return launch_proposal_t<128>(p, B, Rc, S, stream, handled);
+}
+
+}  // namespace frcnn

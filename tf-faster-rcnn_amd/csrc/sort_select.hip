@@ -18,34 +18,9 @@
 // The kernel is latency bound (a few tens of KB per segment); its job is to stay off the host and
 // out of HBM, not to saturate bandwidth.
 #include "sort_select.hpp"
+#include "block_primitives.hpp"
 
 namespace frcnn {
-
-static const int kNT = 1024;
-static const int kNW = 16;
-
-// Exclusive scan of one int per thread over the 1024-thread block; total returned to every thread.
-__device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
-  __syncthreads();  // wsum may still be read from a previous call
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  int base = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < kNW; ++i) {
-    int s = wsum[i];
-    if (i < w) base += s;
-    tot += s;
-  }
-  total = tot;
-  return base + inc - v;
-}
 
 template <typename IdxT>
 __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int c, int n, int K, int use_thr,
@@ -60,119 +35,72 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
   int *misc = wsum + 32;                                               // [32]
   IdxT *orig = reinterpret_cast<IdxT *>(misc + 32);                    // [slots]
   uint16_t *permA = reinterpret_cast<uint16_t *>(orig + slots);        // [slots]
-  uint16_t *permB = permA + slots;                                     // [slots]
+  // permB = permA + slots                                             // [slots] (ping-pong half)
 
   const int seg = blockIdx.x;
   const int b = seg / c;
   const int cls = seg - b * c;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
 
   if (K <= 0 || n <= 0) {
     if (tid == 0 && counts) counts[seg] = 0;
     return;
   }
 
-  // ---- 1. radix select of the K-th smallest key (only when the segment does not fit) ---------
-  uint32_t T = 0xFFFFFFFFu;
-  int need_eq = 0;
-  bool filter = false;  // true: keep key < T, and the first need_eq elements with key == T
-  if (do_select) {
-    if (tid == 0) misc[2] = 0;
-    uint32_t prefix = 0;
-    int need = K;
-    bool all = false;
-    for (int pass = 3; pass >= 0; --pass) {
-      const int shift = pass * 8;
-      if (tid < 256) hist[tid] = 0;
-      __syncthreads();
-      for (int i = tid; i < n; i += kNT) {
-        const float s = load_score(src, b, i, cls);
-        if (!use_thr || s > thr) {
-          const uint32_t k = ~f_order_key(s);
-          if (pass == 3 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-        }
-      }
-      __syncthreads();
-      if (w == 0) {
-        const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-        const uint32_t s4 = h0 + h1 + h2 + h3;
-        uint32_t inc = s4;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
-          if (lane >= off) inc += t;
-        }
-        const uint32_t exc = inc - s4;
-        const bool here = (exc < (uint32_t)need) && (inc >= (uint32_t)need);
-        const unsigned long long bal = __ballot(here);
-        if (bal == 0ull) {
-          if (lane == 0) misc[2] = 1;  // fewer than K candidates in total: keep them all
-        } else if (here) {
-          uint32_t cum = exc;
-          int d = 4 * lane;
-          if (cum + h0 < (uint32_t)need) {
-            cum += h0;
-            ++d;
-            if (cum + h1 < (uint32_t)need) {
-              cum += h1;
-              ++d;
-              if (cum + h2 < (uint32_t)need) {
-                cum += h2;
-                ++d;
-              }
-            }
-          }
-          misc[0] = (int)((prefix << 8) | (uint32_t)d);
-          misc[1] = need - (int)cum;
-        }
-      }
-      __syncthreads();
-      if (misc[2]) {
-        all = true;
-        break;
-      }
-      prefix = (uint32_t)misc[0];
-      need = misc[1];
-    }
-    if (!all) {
-      filter = true;
-      T = prefix;
-      need_eq = need;
-    }
-    __syncthreads();
-  }
-
-  // ---- 2. stable compaction into LDS: thread t owns elements [t*E, (t+1)*E) ---------------------
-  const int E = (n + kNT - 1) / kNT;
-  const int i0 = tid * E;
-  const int i1 = (i0 + E < n) ? (i0 + E) : n;
-  int cnt = 0, eqc = 0;
-  for (int i = i0; i < i1; ++i) {
+  auto keyf = [&](int i, uint32_t &k) -> bool {
     const float s = load_score(src, b, i, cls);
-    if (!use_thr || s > thr) {
-      const uint32_t k = ~f_order_key(s);
-      if (!filter || k < T)
-        ++cnt;
-      else if (k == T)
-        ++eqc;
-    }
-  }
-  int eq_base = 0, tot = 0;
-  if (filter) eq_base = block_excl_scan(eqc, wsum, tot);
-  int sel_eq = 0;
-  if (filter) {
-    sel_eq = need_eq - eq_base;
-    sel_eq = sel_eq < 0 ? 0 : (sel_eq > eqc ? eqc : sel_eq);
-  }
+    k = ~f_order_key(s);
+    return !use_thr || s > thr;
+  };
+
   int V = 0;
-  int pos = block_excl_scan(cnt + sel_eq, wsum, V);
-  // V <= slots by construction (no filter: V <= n == slots; filter: V == K == slots).
-  {
+  if (!do_select && !use_thr) {
+    // ---- top_k of a segment that fits: every element is a candidate, slot == element, coalesced load
+    for (int i = tid; i < n; i += kNT) {
+      uint32_t k;
+      keyf(i, k);
+      keys[i] = k;
+      orig[i] = (IdxT)i;
+      permA[i] = (uint16_t)i;
+    }
+    V = n;
+  } else {
+    // ---- 1. radix select of the K-th smallest key (only when the segment does not fit) ---------
+    uint32_t T = 0xFFFFFFFFu;
+    int need_eq = 0;
+    bool filter = false;  // true: keep key < T, and the first need_eq elements with key == T
+    if (do_select) {
+      bool all;
+      radix_select(keyf, n, K, hist, misc, T, need_eq, all);
+      filter = !all;
+    }
+    // ---- 2. stable compaction into LDS: thread t owns elements [t*E, (t+1)*E) -------------------
+    const int E = (n + kNT - 1) / kNT;
+    const int i0 = tid * E;
+    const int i1 = (i0 + E < n) ? (i0 + E) : n;
+    int cnt = 0, eqc = 0;
+    for (int i = i0; i < i1; ++i) {
+      uint32_t k;
+      if (keyf(i, k)) {
+        if (!filter || k < T)
+          ++cnt;
+        else if (k == T)
+          ++eqc;
+      }
+    }
+    int eq_base = 0, tot = 0;
+    if (filter) eq_base = block_excl_scan(eqc, wsum, tot);
+    int sel_eq = 0;
+    if (filter) {
+      sel_eq = need_eq - eq_base;
+      sel_eq = sel_eq < 0 ? 0 : (sel_eq > eqc ? eqc : sel_eq);
+    }
+    int pos = block_excl_scan(cnt + sel_eq, wsum, V);
+    // V <= slots by construction (no filter: V <= n == slots; filter: V == K <= slots).
     int eq_seen = 0;
     for (int i = i0; i < i1; ++i) {
-      const float s = load_score(src, b, i, cls);
-      if (!use_thr || s > thr) {
-        const uint32_t k = ~f_order_key(s);
+      uint32_t k;
+      if (keyf(i, k)) {
         bool take = !filter || k < T;
         if (filter && k == T) {
           take = (eq_seen < sel_eq);
@@ -186,67 +114,17 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
         }
       }
     }
+    if (V > slots) V = slots;  // defensive; cannot happen
   }
-  if (V > slots) V = slots;  // defensive; cannot happen
 
   // ---- 3. stable LSD radix sort of the V slots --------------------------------------------------
-  const int nchunks = (V + 63) >> 6;
-  const int cpw = (nchunks + kNW - 1) / kNW;
-  const int c0 = w * cpw;
-  const int c1 = (c0 + cpw < nchunks) ? (c0 + cpw) : nchunks;
-  volatile uint32_t *vhist = hist;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass * 8;
-    for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
-    __syncthreads();  // also publishes keys/orig/permA on the first pass
-    for (int ch = c0; ch < c1; ++ch) {
-      const int p = (ch << 6) + lane;
-      if (p < V) {
-        const uint32_t d = (keys[permA[p]] >> shift) & 255u;
-        atomicAdd(&hist[d * kNW + w], 1u);
-      }
-    }
-    __syncthreads();
-    {
-      const uint32_t a0 = hist[4 * tid], a1 = hist[4 * tid + 1], a2 = hist[4 * tid + 2], a3 = hist[4 * tid + 3];
-      int total;
-      const int ex = block_excl_scan((int)(a0 + a1 + a2 + a3), wsum, total);
-      hist[4 * tid] = (uint32_t)ex;
-      hist[4 * tid + 1] = (uint32_t)ex + a0;
-      hist[4 * tid + 2] = (uint32_t)ex + a0 + a1;
-      hist[4 * tid + 3] = (uint32_t)ex + a0 + a1 + a2;
-    }
-    __syncthreads();
-    for (int ch = c0; ch < c1; ++ch) {
-      const int p = (ch << 6) + lane;
-      const bool valid = p < V;
-      const uint32_t id = valid ? (uint32_t)permA[p] : 0u;
-      const uint32_t d = (keys[id] >> shift) & 255u;
-      unsigned long long peers = __ballot(valid);
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const bool on = (d >> bit) & 1u;
-        const unsigned long long bm = __ballot(on);
-        peers &= on ? bm : ~bm;
-      }
-      if (valid) {
-        const uint32_t base = vhist[d * kNW + w];
-        const int r = __popcll(peers & lanemask_lt());
-        permB[base + (uint32_t)r] = (uint16_t)id;
-        if (r == 0) vhist[d * kNW + w] = base + (uint32_t)__popcll(peers);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    uint16_t *t = permA;
-    permA = permB;
-    permB = t;
-  }
+  block_sort_perm(keys, permA, slots, V, hist, wsum);
+  const uint16_t *perm = permA;
 
   // ---- 4. emit ------------------------------------------------------------------------------------
   const int nout = (V < K) ? V : K;
   for (int r = tid; r < nout; r += kNT) {
-    const int i = (int)orig[permA[r]];
+    const int i = (int)orig[perm[r]];
     sorted_idx[(long long)seg * out_stride + r] = i;
     if (sorted_val) sorted_val[(long long)seg * out_stride + r] = load_score(src, b, i, cls);
   }

@@ -1,0 +1,37 @@
+"""Diagnostic only: phase shares of the fused proposal kernel from in-kernel wall_clock64 stamps.
+
+Needs a library built with -DFRCNN_STAMPS ("Diagnostics"); run as
+FRCNN_HIP_LIB=gpurun_out/diag/libfrcnn_hip_stamps.so python tools/diag_stamps.py
+The stamped build's run time is not a benchmark number: read the shares only.
+"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import synth
+import tf_faster_rcnn_amd as pkg
+
+lib = pkg._lib.lib()
+lib.frcnn_debug_stamps.restype = ctypes.c_int
+lib.frcnn_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+anchors = pkg.bbox_utils.generate_anchors(hp)
+d, s = synth.rpn_outputs(0, 16, 32)
+d, s = torch.as_tensor(d).cuda(), torch.as_tensor(s).cuda()
+layer = pkg.faster_rcnn.RoIBBox(anchors, "inference", hp)
+buf = np.zeros(256, dtype=np.int64)
+for it in range(3):
+    layer([d, s])
+    torch.cuda.synchronize()
+    n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    if it == 2:
+        tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+        cyc = buf[0:2 * n:2] & 0xFFFFFFFFFFFF
+        print("shader clock MHz over the kernel:", (cyc[n - 1] - cyc[0]) / ((t[n - 1] - t[0]) * 0.01))
+        print("n stamps", n)
+        for i in range(n):
+            print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
