@@ -265,7 +265,7 @@ static int launch_nms_t(const NmsParams &p, long long S, int Rc, hipStream_t str
 }
 
 static int launch_nms(const NmsParams &p, long long S, hipStream_t stream) {
-  int Rc = (p.R + 7) & ~7;
+  int Rc = (p.R + 7) & ~7;  // multiple of 4: LDS sub-array alignment
   if (Rc < 8) Rc = 8;
   // Few candidates per segment (Decoder: <= R RoIs per class) -> 4 waves, 64-wide chunks;
   // many (RPN proposals) -> 16 waves, 256-wide chunks.

@@ -8,31 +8,25 @@ namespace frcnn {
 
 static const int kMaxKept = 5000;  // kept-list capacity in LDS (28 B per entry)
 
-// ---- exact, division-free form of TF's "iou > iou_threshold" ------------------------------------------
-// With q = fl32(inter / uni) (round to nearest even) and thr' the next fp32 above thr:
-//   q > thr  <=>  q >= thr'  <=>  inter/uni >= mid (or > mid), mid = (thr + thr') / 2,
-// where the tie case inter/uni == mid rounds to the even neighbour: up (to thr') iff the bit pattern of
-// thr is odd.  For uni > 0 this is inter >= mid * uni, and mid * uni is EXACT in fp64 (25 x 24 significant
-// bits), so the comparison reproduces the fp32 division bit for bit without dividing (checked against
-// the division on near-threshold pairs in tests/test_host.py).  Anything irregular (uni not a positive
-// finite number, non-finite threshold, non-finite box coordinates) takes the reference formulation.
+// ---- TF's "iou > iou_threshold" without the division ------------------------------------------------
+// The reference computes q = fl32(inter / uni) and tests q > thr.  With thr' the next fp32 above thr and
+// mid = (thr + thr') / 2, that is  inter/uni > mid  (>= when the tie rounds up), so the sign of
+// inter - mid * uni decides.  fp32 suffices away from the boundary:
+//   t = fl(thr * uni) is within 2^-24 (relative) of thr * uni and mid is within 2^-24 of thr, so
+//   inter > t * (1 + 2^-21)  =>  true,      inter < t * (1 - 2^-21)  =>  false,
+// and only the pairs inside that 2^-20-wide band (about one in a million near-threshold pairs), irregular
+// operands (uni outside [1e-30, 1e30], non-finite coordinates) or unusual thresholds (outside [1e-6, 1e6])
+// are re-evaluated with the reference formulation, division included (nms_iou_gt).  The fast and the
+// reference forms therefore agree on every input; tests/test_host.py checks the band logic on the CPU.
 struct IouThr {
-  double mid;
   float thr;
-  int tie_up;
   int slow_only;
 };
 
 static inline IouThr make_iou_thr(float thr) {
   IouThr t;
   t.thr = thr;
-  t.slow_only = !(thr == thr) || thr > 3.402823466e+38f || thr < -3.402823466e+38f;
-  float z = (thr == 0.0f) ? 0.0f : thr;  // -0 -> +0
-  uint32_t bits;
-  __builtin_memcpy(&bits, &z, 4);
-  t.tie_up = (int)(bits & 1u);
-  float nxt = __builtin_nextafterf(z, __builtin_huge_valf());
-  t.mid = t.slow_only ? 0.0 : ((double)z + (double)nxt) * 0.5;
+  t.slow_only = !(thr >= 1e-6f && thr <= 1e6f);
   return t;
 }
 
@@ -46,8 +40,40 @@ __device__ __forceinline__ int box_flags(float4 b, const NBox &nb) {
   return (!(nb.area <= 0.0f) ? kFlagArea : 0) | (finite ? 0 : kFlagSpecial);
 }
 
-// i, j: corner-normalised boxes; fi, fj: their flags.  Same value as nms_iou_gt(i, j, thr) for every input.
-__device__ __forceinline__ bool nms_iou_gt_fast(const NBox &i, int fi, const NBox &j, int fj, const IouThr &t) {
+// Packed candidate: corner-normalised box + area + flags (LDS: one float4 and one float2 per candidate,
+// so a broadcast row costs a ds_read_b128 and a ds_read_b64 instead of six ds_read_b32).
+struct PBox {
+  float ymin, xmin, ymax, xmax, area;
+  int flag;
+};
+
+__device__ __forceinline__ PBox load_pbox(const float4 *box, const float2 *af, int i) {
+  const float4 b = box[i];
+  const float2 a = af[i];
+  PBox p;
+  p.ymin = b.x;
+  p.xmin = b.y;
+  p.ymax = b.z;
+  p.xmax = b.w;
+  p.area = a.x;
+  p.flag = __float_as_int(a.y);
+  return p;
+}
+
+__device__ __forceinline__ NBox to_nbox(const PBox &p) {
+  NBox n;
+  n.ymin = p.ymin;
+  n.xmin = p.xmin;
+  n.ymax = p.ymax;
+  n.xmax = p.xmax;
+  n.area = p.area;
+  return n;
+}
+
+// Straight-line filter form of nms_iou_gt; `irr` is OR-ed with "this pair must be re-evaluated with
+// nms_iou_gt" (the caller does that once per group of tests, which keeps the group free of branches so
+// that independent tests overlap).
+__device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, const IouThr &t, bool &irr) {
   // finite coordinates: v_max/v_min equal std::max/std::min up to the sign of zero, which cannot change
   // the outcome (it only reaches comparisons and products with exact zeros)
   float ih = __builtin_fminf(i.ymax, j.ymax) - __builtin_fmaxf(i.ymin, j.ymin);
@@ -57,14 +83,16 @@ __device__ __forceinline__ bool nms_iou_gt_fast(const NBox &i, int fi, const NBo
   const float inter = ih * iw;
   float uni = i.area + j.area;
   uni = uni - inter;
-  const double pr = t.mid * (double)uni;
-  const double di = (double)inter;
-  bool res = t.tie_up ? (di >= pr) : (di > pr);
-  res = res && ((fi & fj & kFlagArea) != 0);
-  // positive normal or subnormal uni (class mask 0x180), regular threshold, finite coordinates
-  const bool regular = __builtin_amdgcn_classf(uni, 0x180) && !t.slow_only && (((fi | fj) & kFlagSpecial) == 0);
-  if (__builtin_expect(!regular, 0)) res = nms_iou_gt(i, j, t.thr);
-  return res;
+  const float tt = t.thr * uni;
+  const float hi = tt * 1.000000476837158203125f;  // 1 + 2^-21
+  const float lo = tt * 0.999999523162841796875f;  // 1 - 2^-21
+  const bool yes = inter > hi;
+  const bool no = inter < lo;
+  const bool area_ok = (i.flag & j.flag & kFlagArea) != 0;
+  const bool regular = (uni >= 1e-30f) & (uni <= 1e30f) & (((i.flag | j.flag) & kFlagSpecial) == 0);
+  // irregular or inside the band: exact re-evaluation needed (unless TF's area guard already says "no")
+  irr = irr | (area_ok & !(regular & (yes | no)));
+  return yes & area_ok;
 }
 
 // LDS layout for chunks of CH candidates (CH = 64 * G).
@@ -72,40 +100,33 @@ template <int CH>
 struct NmsLds {
   unsigned long long *mask;  // [CH * G] intra-chunk suppression words, mask[row * G + column group]
   unsigned long long *dead;  // [4]
-  float *c_ymin, *c_xmin, *c_ymax, *c_xmax, *c_area;  // [CH] chunk boxes (corner-normalised)
-  int *c_idx;                                         // [CH] element index of each chunk candidate
-  int *c_flag;                                        // [CH]
-  int *s_nk;                                          // [4]
-  float *k_ymin, *k_xmin, *k_ymax, *k_xmax, *k_area;  // [Rc] kept boxes
-  int *k_idx;                                         // [Rc]
-  int *k_flag;                                        // [Rc]
+  float4 *c_box;             // [CH] chunk boxes (corner-normalised)
+  float2 *c_af;              // [CH] (area, flags)
+  int *c_idx;                // [CH] element index of each chunk candidate
+  int *s_nk;                 // [4]
+  float4 *k_box;             // [Rc] kept boxes
+  float2 *k_af;              // [Rc]
+  int *k_idx;                // [Rc]
 };
 
 template <int CH>
 __host__ __device__ static inline size_t nms_lds_bytes(int Rc) {
-  return (size_t)CH * (CH / 64) * 8 + 4 * 8 + (size_t)CH * 7 * 4 + 4 * 4 + (size_t)Rc * 7 * 4;
+  return (size_t)CH * (CH / 64) * 8 + 4 * 8 + (size_t)CH * 28 + 4 * 4 + (size_t)Rc * 28;
 }
 
+// Rc must be a multiple of 4 (keeps every sub-array 16-byte aligned).
 template <int CH>
 __device__ __forceinline__ NmsLds<CH> carve_nms_lds(unsigned char *smem, int Rc) {
   NmsLds<CH> L;
   L.mask = reinterpret_cast<unsigned long long *>(smem);
   L.dead = L.mask + CH * (CH / 64);
-  L.c_ymin = reinterpret_cast<float *>(L.dead + 4);
-  L.c_xmin = L.c_ymin + CH;
-  L.c_ymax = L.c_xmin + CH;
-  L.c_xmax = L.c_ymax + CH;
-  L.c_area = L.c_xmax + CH;
-  L.c_idx = reinterpret_cast<int *>(L.c_area + CH);
-  L.c_flag = L.c_idx + CH;
-  L.s_nk = L.c_flag + CH;
-  L.k_ymin = reinterpret_cast<float *>(L.s_nk + 4);
-  L.k_xmin = L.k_ymin + Rc;
-  L.k_ymax = L.k_xmin + Rc;
-  L.k_xmax = L.k_ymax + Rc;
-  L.k_area = L.k_xmax + Rc;
-  L.k_idx = reinterpret_cast<int *>(L.k_area + Rc);
-  L.k_flag = L.k_idx + Rc;
+  L.c_box = reinterpret_cast<float4 *>(L.dead + 4);
+  L.k_box = L.c_box + CH;
+  L.c_af = reinterpret_cast<float2 *>(L.k_box + Rc);
+  L.k_af = L.c_af + CH;
+  L.c_idx = reinterpret_cast<int *>(L.k_af + Rc);
+  L.k_idx = L.c_idx + CH;
+  L.s_nk = L.k_idx + Rc;
   return L;
 }
 
@@ -151,46 +172,39 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       nb = normalise_box(box);
       fl = box_flags(box, nb);
     }
-    L.c_ymin[tid] = nb.ymin;
-    L.c_xmin[tid] = nb.xmin;
-    L.c_ymax[tid] = nb.ymax;
-    L.c_xmax[tid] = nb.xmax;
-    L.c_area[tid] = nb.area;
+    L.c_box[tid] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
+    L.c_af[tid] = make_float2(nb.area, __int_as_float(fl));
     L.c_idx[tid] = ei;
-    L.c_flag[tid] = fl;
     const unsigned long long badw = __ballot(bad);  // candidates that fail the score threshold start dead
     if (lane == 0) L.dead[w] = badw;
   }
   __syncthreads();
   FRCNN_STAMP(10);
 
-  // ---- a. chunk vs kept list ------------------------------------------------------------------
+  // ---- a. chunk vs kept list, four kept boxes per step -------------------------------------------
   if (nk > 0) {
     const int j = tid & (CH - 1);
     const int slice = tid / CH;
     if ((j & ~63) < nc) {  // wave-uniform: this wave's 64 candidates exist
-      NBox me;
-      me.ymin = L.c_ymin[j];
-      me.xmin = L.c_xmin[j];
-      me.ymax = L.c_ymax[j];
-      me.xmax = L.c_xmax[j];
-      me.area = L.c_area[j];
-      const int mf = L.c_flag[j];
+      const PBox me = load_pbox(L.c_box, L.c_af, j);
       bool d = false;
       for (int k0 = slice; k0 < nk; k0 += 4 * NSL) {
+        PBox kb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int k = k0 + u * NSL;
-          if (k < nk) {  // wave-uniform
-            NBox kb;
-            kb.ymin = L.k_ymin[k];
-            kb.xmin = L.k_xmin[k];
-            kb.ymax = L.k_ymax[k];
-            kb.xmax = L.k_xmax[k];
-            kb.area = L.k_area[k];
-            d = d | nms_iou_gt_fast(me, mf, kb, L.k_flag[k], thr);
-          }
+          int k = k0 + u * NSL;
+          k = k < nk ? k : nk - 1;  // clamp: re-testing a kept box is harmless
+          kb[u] = load_pbox(L.k_box, L.k_af, k);
         }
+        bool irr = false, dd = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], thr, irr);
+        if (__builtin_expect(__any(irr || thr.slow_only), 0)) {
+          dd = false;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), thr.thr);
+        }
+        d = d | dd;
         if (__all(d || (j >= nc))) break;
       }
       const unsigned long long word = __ballot(d && (j < nc));
@@ -199,7 +213,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
   }
   FRCNN_STAMP(11);
 
-  // ---- b. intra-chunk IoU tiles (upper triangle), ROWS rows per work item ------------------------
+  // ---- b. intra-chunk IoU tiles (upper triangle), ROWS rows per work item, four rows per step ----
   for (int item = w; item < TILES * SPLIT; item += NWV) {
     const int tile = item / SPLIT;
     const int part = item - tile * SPLIT;
@@ -215,25 +229,26 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
     const int cg = rg + rem;
     if (rg * 64 >= nc || cg * 64 >= nc) continue;  // wave-uniform
     const int jcol = cg * 64 + lane;
-    NBox me;
-    me.ymin = L.c_ymin[jcol];
-    me.xmin = L.c_xmin[jcol];
-    me.ymax = L.c_ymax[jcol];
-    me.xmax = L.c_xmax[jcol];
-    me.area = L.c_area[jcol];
-    const int mf = L.c_flag[jcol];
-#pragma unroll 8
-    for (int ii = 0; ii < ROWS; ++ii) {
-      const int irow = rg * 64 + part * ROWS + ii;
-      NBox rb;
-      rb.ymin = L.c_ymin[irow];
-      rb.xmin = L.c_xmin[irow];
-      rb.ymax = L.c_ymax[irow];
-      rb.xmax = L.c_xmax[irow];
-      rb.area = L.c_area[irow];
-      const bool bit = (irow < jcol) & (jcol < nc) & nms_iou_gt_fast(rb, L.c_flag[irow], me, mf, thr);
-      const unsigned long long word = __ballot(bit);
-      if (lane == 0) L.mask[irow * G + cg] = word;
+    const PBox me = load_pbox(L.c_box, L.c_af, jcol);
+    static_assert(ROWS % 4 == 0, "rows per item must be a multiple of 4");
+    for (int i0 = 0; i0 < ROWS; i0 += 4) {
+      const int irow0 = rg * 64 + part * ROWS + i0;
+      PBox rb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rb[u] = load_pbox(L.c_box, L.c_af, irow0 + u);
+      bool irr = false;
+      bool bit[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, thr, irr);
+      if (__builtin_expect(__any(irr || thr.slow_only), 0)) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), thr.thr);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned long long word = __ballot(bit[u] & (irow0 + u < jcol) & (jcol < nc));
+        if (lane == 0) L.mask[(irow0 + u) * G + cg] = word;
+      }
     }
   }
   __syncthreads();
@@ -293,13 +308,9 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
             if (w2 > g && row[w2] != 0ull) atomicOr(&L.dead[w2], row[w2]);
           const int pos = nk + __popcll(keptbits & lanemask_lt());
           const int j = g * 64 + lane;
-          L.k_ymin[pos] = L.c_ymin[j];
-          L.k_xmin[pos] = L.c_xmin[j];
-          L.k_ymax[pos] = L.c_ymax[j];
-          L.k_xmax[pos] = L.c_xmax[j];
-          L.k_area[pos] = L.c_area[j];
+          L.k_box[pos] = L.c_box[j];
+          L.k_af[pos] = L.c_af[j];
           L.k_idx[pos] = L.c_idx[j];
-          L.k_flag[pos] = L.c_flag[j];
         }
         nk += __popcll(keptbits);
       }
