@@ -6,7 +6,7 @@ The directory name carries a hyphen (the project's name); import it as ``tf_fast
 reference's ``models/faster_rcnn.py``, ``utils/bbox_utils.py`` and ``utils/train_utils.py``.
 """
 
-from . import _lib  # noqa: F401
+from . import _lib, sharding  # noqa: F401
 from .models import faster_rcnn  # noqa: F401
 from .utils import bbox_utils, train_utils  # noqa: F401
 
