@@ -364,6 +364,32 @@ def test_decoder(pkg, B, R, L):
         assert_bits(g, w, f"Decoder {name}")
 
 
+def test_decoder_unfused_path(pkg, monkeypatch):
+    """The generic sort -> NMS -> merge pipeline behind frcnn_decoder (taken when the fused kernel does not fit)."""
+    monkeypatch.setenv("FRCNN_DECODER_UNFUSED", "1")
+    test_decoder(pkg, 16, 300, 21)
+    test_decoder_unnormalised_scores(pkg)
+
+
+def test_decoder_many_candidates_per_class(pkg):
+    """More than 64 candidates in one class (several NMS tiles per class) and more than 1024 candidates per image
+    (radix-sort branch of the fused kernel), with heavy suppression."""
+    hp = synth.hyper_params()
+    B, R, L = 2, 300, 6
+    rng = np.random.default_rng(77)
+    c = rng.random((B, R, 2)) * 0.5 + 0.25
+    hw = rng.uniform(0.1, 0.2, (B, R, 2))
+    rois = np.concatenate([c - hw, c + hw], -1).astype(np.float32)
+    deltas = rng.normal(0, 0.3, (B, R, L * 4)).astype(np.float32)
+    probs = rng.random((B, R, L)).astype(np.float32)  # ~ R*(L-1)/2*... > 1024 candidates above 0.2 per image
+    for thr, T in ((0.2, 200), (0.9, 50)):
+        layer = pkg.faster_rcnn.Decoder(hp["variances"], L, max_total_size=T, score_threshold=thr)
+        got = layer([dev(rois), dev(deltas), dev(probs)])
+        want = oracle.decoder(rois, deltas, probs, hp["variances"], L, T, thr)
+        for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
+            assert_bits(g, w, f"Decoder dense thr={thr} {name}")
+
+
 def test_decoder_unnormalised_scores(pkg):
     """Un-normalised scores: several classes (incl. class 0) above threshold per RoI, cross-class ties."""
     hp = synth.hyper_params()

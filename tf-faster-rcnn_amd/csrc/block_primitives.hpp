@@ -125,28 +125,29 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
   __syncthreads();
 }
 
-// Stable least-significant-digit radix sort (4 passes of 8 bits) of V slot numbers by keys[slot].
-// perm[0..V) holds the initial order (normally 0..V-1) and, after the even number of passes, the sorted
-// order; perm[stride..stride+V) is the ping-pong scratch.  (The two halves are addressed through one base
-// pointer and an integer offset: selecting between two LDS pointers makes hipcc 7.2 emit an illegal
-// null-check on src_shared_base.)  hist: kNW*256 uint32 of LDS; wsum: kNW ints.  V <= 65536.
-__device__ __forceinline__ void block_sort_perm(const uint32_t *keys, uint16_t *perm, int stride, int V,
-                                                uint32_t *hist, int *wsum) {
+// Stable least-significant-digit radix sort of V slot numbers: `npass` passes of 8 bits, digit(slot, pass)
+// gives the pass's digit of a slot (pass 0 = least significant).  perm[0..V) holds the initial order
+// (normally 0..V-1); perm[stride..stride+V) is the ping-pong half.  Returns the offset (0 or stride) of the
+// half that holds the sorted order.  (The two halves are addressed through one base pointer and an integer
+// offset: selecting between two LDS pointers makes hipcc 7.2 emit an illegal null-check on
+// src_shared_base.)  hist: kNW*256 uint32 of LDS; wsum: kNW ints.  V <= 65536.
+template <class DigitF>
+__device__ __forceinline__ int block_sort_digits(DigitF digit, int npass, uint16_t *perm, int stride, int V,
+                                                 uint32_t *hist, int *wsum) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nchunks = (V + 63) >> 6;
   const int cpw = (nchunks + kNW - 1) / kNW;
   const int c0 = w * cpw;
   const int c1 = (c0 + cpw < nchunks) ? (c0 + cpw) : nchunks;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass * 8;
+  for (int pass = 0; pass < npass; ++pass) {
     const int src = (pass & 1) ? stride : 0;
     const int dst = stride - src;
     for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
-    __syncthreads();  // also publishes keys / permA on the first pass
+    __syncthreads();  // also publishes the caller's keys / perm on the first pass
     for (int ch = c0; ch < c1; ++ch) {
       const int p = (ch << 6) + lane;
       const bool valid = p < V;
-      const uint32_t d = valid ? ((keys[perm[src + p]] >> shift) & 255u) : 0u;
+      const uint32_t d = valid ? (digit((int)perm[src + p], pass) & 255u) : 0u;
       hist_add(hist, d * kNW + w, valid);
     }
     __syncthreads();
@@ -164,7 +165,7 @@ __device__ __forceinline__ void block_sort_perm(const uint32_t *keys, uint16_t *
       const int p = (ch << 6) + lane;
       const bool valid = p < V;
       const uint32_t id = valid ? (uint32_t)perm[src + p] : 0u;
-      const uint32_t d = (keys[id] >> shift) & 255u;
+      const uint32_t d = digit((int)id, pass) & 255u;
       unsigned long long peers = __ballot(valid);
 #pragma unroll
       for (int bit = 0; bit < 8; ++bit) {
@@ -185,6 +186,14 @@ __device__ __forceinline__ void block_sort_perm(const uint32_t *keys, uint16_t *
     }
     __syncthreads();
   }
+  return (npass & 1) ? stride : 0;
+}
+
+// The common case: 4 passes over 32-bit keys[slot]; the sorted order ends up in perm[0..V).
+__device__ __forceinline__ void block_sort_perm(const uint32_t *keys, uint16_t *perm, int stride, int V,
+                                                uint32_t *hist, int *wsum) {
+  block_sort_digits([&](int slot, int pass) -> uint32_t { return keys[slot] >> (8 * pass); }, 4, perm, stride, V, hist,
+                    wsum);
 }
 
 }  // namespace frcnn

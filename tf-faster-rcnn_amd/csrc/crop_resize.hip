@@ -133,7 +133,10 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(
     int p = tid / CV;
     int c = tid - p * CV;
     const int dp = 256 / CV, dc = 256 - dp * CV;
-#pragma unroll 4
+#ifndef FRCNN_CROP_UNROLL
+#define FRCNN_CROP_UNROLL 4
+#endif
+#pragma unroll FRCNN_CROP_UNROLL
     for (int e = tid; e < total; e += 256) {
       const PixParam prm = pp[p];
       const vec_t tl = img[prm.off_tl + c];
@@ -150,7 +153,11 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(
       t = t * prm.ly;
       vec_t v = tp + t;
       if (!prm.valid) v = (vec_t)(extrap);
+#ifdef FRCNN_CROP_PLAIN_STORE
+      dst[e] = v;
+#else
       __builtin_nontemporal_store(v, &dst[e]);
+#endif
       c += dc;
       p += dp;
       if (c >= CV) {

@@ -1,0 +1,408 @@
+// decoder.hip -- the Decoder layer as ONE kernel: background masking, per-class candidate lists, per-class
+// greedy NMS and the cross-class top-T merge, one workgroup per image.
+//
+// Replaces models/faster_rcnn.py:74-91 (reshape, * variances, tile, get_bboxes_from_deltas, argmax / where,
+// combined_non_max_suppression with 200 per class / 200 total, score_threshold, IoU 0.5, clip_boxes).
+//
+// Per image (1024 threads, everything in LDS):
+//   A. one lane per RoI row: first-max argmax over the L probabilities; rows whose argmax is background
+//      contribute nothing, otherwise every class with prob > score_threshold is a candidate.  Candidates
+//      are compacted in (roi, class) order with a block prefix scan.  With softmax inputs there is at most
+//      one candidate per RoI; un-normalised scores may give up to R*L.
+//   B. candidates are ordered by (class asc, score desc, roi asc): up to 1024 of them by counting ranks
+//      (each lane counts the keys that precede its own; all reads are LDS broadcasts), more by the stable
+//      LSD radix sort (4 score passes + 1 class pass).
+//   C. the classes are shared out over the NMS waves; each wave runs greedy NMS on its class segments in
+//      64-candidate tiles: lane = candidate, box decoded on the fly from (roi, delta * variance), test
+//      against the wave's kept list, 64x64 intra-tile mask by __ballot, scalar greedy resolve.
+//      The (B,R,L,4) decoded tensor of the reference is never materialised.
+//   D. every kept entry finds its rank in the cross-class (score desc, class asc, selection order)
+//      ordering by binary searches in the other classes' kept lists; ranks < T are decoded once more,
+//      clipped to [0,1] and written; the remaining rows are zero padding.
+// Latency bound (~2 MB of traffic per batch of 16): judged on images/s.
+#include <stdlib.h>
+
+#include "block_primitives.hpp"
+#include "nms_core.hpp"
+
+namespace frcnn {
+
+struct DecoderParams {
+  const float *rois;    // (B,R,4)
+  const float *deltas;  // (B,R,L,4)
+  const float *probs;   // (B,R,L)
+  float v0, v1, v2, v3;
+  int R, L, T, Rpc;     // Rpc = min(max_output_size_per_class, R)
+  float score_thr;
+  IouThr iou;
+  float *out_boxes;   // (B,T,4)
+  float *out_labels;  // (B,T) or NULL
+  float *out_scores;  // (B,T) or NULL
+  int *out_valid;     // (B) or NULL
+};
+
+static const int kDecMaxClasses = 256;
+
+// per-NMS-wave LDS: one 64-candidate tile + the kept list of the class being processed
+__host__ __device__ static inline size_t dec_wave_bytes(int Rpc4) { return (size_t)(64 + Rpc4) * 24; }
+
+__host__ __device__ static inline size_t dec_lds_bytes(int Vcap, int Rpc4, int nms_waves) {
+  return (size_t)Vcap * (4 + 4 + 2 + 2 + 2) + (size_t)kNW * 256 * 4 + 64 * 4 + (size_t)3 * (kDecMaxClasses + 4) * 4 +
+         (size_t)nms_waves * dec_wave_bytes(Rpc4);
+}
+
+__global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // wave areas first (float4 alignment), then the 4-byte and 2-byte arrays
+  unsigned char *wave_area = smem;
+  uint32_t *key = reinterpret_cast<uint32_t *>(smem + (size_t)nms_waves * dec_wave_bytes(Rpc4));  // [Vcap] ascending = score desc
+  uint32_t *pk = key + Vcap;                                  // [Vcap] (class << 24) | roi
+  uint32_t *hist = pk + Vcap;                                 // [kNW*256]
+  int *wsum = reinterpret_cast<int *>(hist + kNW * 256);      // [32]
+  int *misc = wsum + 32;                                      // [32]
+  int *ccount = misc + 32;                                    // [260] candidates per class
+  int *cstart = ccount + kDecMaxClasses + 4;                  // [260] first sorted position of a class
+  int *kcount = cstart + kDecMaxClasses + 4;                  // [260] kept per class
+  uint16_t *perm = reinterpret_cast<uint16_t *>(kcount + kDecMaxClasses + 4);  // [2*Vcap]
+  uint16_t *klist = perm + 2 * Vcap;                          // [Vcap] kept slots; class c at klist[cstart[c] ..]
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int R = p.R, L = p.L, T = p.T;
+  const float *probs = p.probs + (long long)b * R * L;
+  const float4 *rois = reinterpret_cast<const float4 *>(p.rois) + (long long)b * R;
+  const float4 *deltas = reinterpret_cast<const float4 *>(p.deltas) + (long long)b * R * L;
+
+  auto box_of = [&](int r, int cls) -> float4 {
+    return decode_box(rois[r], scale_deltas(deltas[(long long)r * L + cls], p.v0, p.v1, p.v2, p.v3));
+  };
+
+  for (int i = tid; i < 3 * (kDecMaxClasses + 4); i += kNT) ccount[i] = 0;  // ccount, cstart, kcount are contiguous
+  __syncthreads();
+
+  // ---- A. candidates, compacted in (roi, class) order -------------------------------------------------
+  const int E = (R + kNT - 1) / kNT;
+  const int r0 = tid * E;
+  const int r1 = (r0 + E < R) ? (r0 + E) : R;
+  int cnt = 0;
+  for (int r = r0; r < r1; ++r) {
+    const float *row = probs + (long long)r * L;
+    float best = -3.402823466e+38f;  // [TF-recall] tf.argmax: first maximal index (strict '>' from lowest())
+    int am = 0;
+    for (int l = 0; l < L; ++l) {
+      const float v = row[l];
+      if (v > best) {
+        best = v;
+        am = l;
+      }
+    }
+    if (am != 0)
+      for (int l = 0; l < L; ++l) cnt += (row[l] > p.score_thr);
+  }
+  int V;
+  int pos = block_excl_scan(cnt, wsum, V);
+  for (int r = r0; r < r1; ++r) {
+    const float *row = probs + (long long)r * L;
+    float best = -3.402823466e+38f;
+    int am = 0;
+    for (int l = 0; l < L; ++l) {
+      const float v = row[l];
+      if (v > best) {
+        best = v;
+        am = l;
+      }
+    }
+    if (am != 0) {
+      for (int l = 0; l < L; ++l) {
+        const float v = row[l];
+        if (v > p.score_thr && pos < Vcap) {
+          key[pos] = ~f_order_key(v);
+          pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
+          perm[pos] = (uint16_t)pos;
+          atomicAdd(&ccount[l], 1);
+          ++pos;
+        }
+      }
+    }
+  }
+  if (V > Vcap) V = Vcap;  // cannot happen: Vcap >= R*L
+  __syncthreads();
+
+  // ---- B. order by (class asc, score desc, roi asc) -----------------------------------------------------
+  int soff = 0;  // offset of the sorted order inside perm
+  if (V <= kNT) {
+    uint64_t mine = 0;
+    if (tid < V) mine = ((uint64_t)(pk[tid] >> 24) << 32) | key[tid];
+    int rank = 0;
+    for (int j = 0; j < V; ++j) {  // LDS broadcast reads
+      const uint64_t other = ((uint64_t)(pk[j] >> 24) << 32) | key[j];
+      rank += (other < mine) || (other == mine && j < tid);
+    }
+    __syncthreads();
+    if (tid < V) perm[rank] = (uint16_t)tid;
+    __syncthreads();
+  } else {
+    soff = block_sort_digits(
+        [&](int slot, int pass) -> uint32_t { return pass < 4 ? (key[slot] >> (8 * pass)) : (pk[slot] >> 24); }, 5, perm,
+        Vcap, V, hist, wsum);
+  }
+  const uint16_t *sperm = perm + soff;
+  // class segment starts: exclusive prefix of ccount (wave 0, 4 classes per lane)
+  if (w == 0) {
+    const int c0 = ccount[4 * lane], c1 = ccount[4 * lane + 1], c2 = ccount[4 * lane + 2], c3 = ccount[4 * lane + 3];
+    int inc = c0 + c1 + c2 + c3;
+    const int s4 = inc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    const int ex = inc - s4;
+    cstart[4 * lane] = ex;
+    cstart[4 * lane + 1] = ex + c0;
+    cstart[4 * lane + 2] = ex + c0 + c1;
+    cstart[4 * lane + 3] = ex + c0 + c1 + c2;
+  }
+  __syncthreads();
+
+  // ---- C. per-class greedy NMS, one wave per class segment ------------------------------------------------
+  if (w < nms_waves) {
+    float4 *cbox = reinterpret_cast<float4 *>(wave_area + (size_t)w * dec_wave_bytes(Rpc4));
+    float4 *kbox = cbox + 64;
+    float2 *caf = reinterpret_cast<float2 *>(kbox + Rpc4);
+    float2 *kaf = caf + 64;
+    for (int cls = w; cls < L; cls += nms_waves) {
+      const int s0 = cstart[cls];
+      const int m = ccount[cls];
+      const int Rk = (p.Rpc < m) ? p.Rpc : m;
+      int nk = 0;
+      for (int base = 0; base < m && nk < Rk; base += 64) {
+        const int nc = (m - base < 64) ? (m - base) : 64;
+        // load the tile: lane = candidate
+        PBox me;
+        me.ymin = me.xmin = me.ymax = me.xmax = me.area = 0.0f;
+        me.flag = 0;
+        int slot = 0;
+        if (lane < nc) {
+          slot = (int)sperm[s0 + base + lane];
+          const float4 box = box_of((int)(pk[slot] & 0xFFFFFFu), cls);
+          const NBox nb = normalise_box(box);
+          me.ymin = nb.ymin;
+          me.xmin = nb.xmin;
+          me.ymax = nb.ymax;
+          me.xmax = nb.xmax;
+          me.area = nb.area;
+          me.flag = box_flags(box, nb);
+        }
+        cbox[lane] = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+        caf[lane] = make_float2(me.area, __int_as_float(me.flag));
+        __builtin_amdgcn_wave_barrier();
+        // a. against the kept list of this class
+        bool d = false;
+        for (int k0 = 0; k0 < nk; k0 += 4) {
+          PBox kb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) kb[u] = load_pbox(kbox, kaf, (k0 + u < nk) ? (k0 + u) : (nk - 1));
+          bool irr = false, dd = false;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], p.iou, irr);
+          if (__builtin_expect(__any(irr || p.iou.slow_only), 0)) {
+            dd = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), p.iou.thr);
+          }
+          d = d | dd;
+          if (__all(d || (lane >= nc))) break;
+        }
+        // b. intra-tile mask: row i suppresses column lane (i < lane)
+        unsigned long long own = 0ull;
+        for (int i0 = 0; i0 < nc; i0 += 4) {
+          PBox rb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rb[u] = load_pbox(cbox, caf, (i0 + u < 64) ? (i0 + u) : 63);
+          bool irr = false;
+          bool bit[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, p.iou, irr);
+          if (__builtin_expect(__any(irr || p.iou.slow_only), 0)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), p.iou.thr);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned long long word = __ballot(bit[u] & (i0 + u < lane) & (lane < nc));
+            if (lane == i0 + u) own = word;
+          }
+        }
+        // c. greedy resolve (scalar), rows that suppress nothing are accepted in bulk
+        const unsigned long long rem0 = __ballot(d);
+        const unsigned long long nz = __ballot(own != 0ull);
+        const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
+        unsigned long long rem = uniform64(rem0);
+        unsigned long long alive = uniform64(~rem & valid);
+        unsigned long long keptbits = 0ull;
+        int cnt2 = nk;
+        while (alive != 0ull && cnt2 < Rk) {
+          const unsigned long long nza = alive & nz;
+          const int f = (nza != 0ull) ? (int)__builtin_ctzll(nza) : 64;
+          unsigned long long batch = (f >= 64) ? alive : (alive & ((1ull << f) - 1ull));
+          int nb = __popcll(batch);
+          if (nb > 0) {
+            if (cnt2 + nb > Rk) {
+              unsigned long long t = 0ull, bb = batch;
+              for (int k = cnt2; k < Rk; ++k) {
+                const unsigned long long low = bb & (0ull - bb);
+                t |= low;
+                bb ^= low;
+              }
+              batch = t;
+              nb = Rk - cnt2;
+            }
+            keptbits |= batch;
+            cnt2 += nb;
+            alive &= ~batch;
+            if (cnt2 >= Rk) break;
+          }
+          if (f < 64) {
+            keptbits |= (1ull << f);
+            ++cnt2;
+            rem |= readlane64(own, f);
+            alive &= ~(rem | keptbits);
+          }
+        }
+        if ((keptbits >> lane) & 1ull) {
+          const int kp = nk + __popcll(keptbits & lanemask_lt());
+          kbox[kp] = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+          kaf[kp] = make_float2(me.area, __int_as_float(me.flag));
+          klist[s0 + kp] = (uint16_t)slot;
+        }
+        nk += __popcll(keptbits);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) kcount[cls] = nk;
+    }
+  }
+  __syncthreads();
+
+  // ---- D. cross-class merge: rank of every kept entry, output ------------------------------------------------
+  // koff (exclusive prefix of kcount) reuses ccount; wave 0 scans.
+  int *koff = ccount;
+  if (w == 0) {
+    const int c0 = kcount[4 * lane], c1 = kcount[4 * lane + 1], c2 = kcount[4 * lane + 2], c3 = kcount[4 * lane + 3];
+    int inc = c0 + c1 + c2 + c3;
+    const int s4 = inc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    const int ex = inc - s4;
+    koff[4 * lane] = ex;
+    koff[4 * lane + 1] = ex + c0;
+    koff[4 * lane + 2] = ex + c0 + c1;
+    koff[4 * lane + 3] = ex + c0 + c1 + c2;
+    if (lane == 63) misc[0] = inc;
+  }
+  __syncthreads();
+  const int total = misc[0];
+  const int nvalid = total < T ? total : T;
+  for (int e = tid; e < total; e += kNT) {
+    int cls;
+    {
+      int lo = 0, hi = L - 1;  // last class with koff[cls] <= e
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (koff[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      cls = lo;
+    }
+    const int kpos = e - koff[cls];
+    const int slot = (int)klist[cstart[cls] + kpos];
+    const uint32_t mykey = key[slot];
+    int rank = kpos;
+    for (int c2 = 0; c2 < L; ++c2) {
+      const int n2 = kcount[c2];
+      if (c2 == cls || n2 == 0) continue;
+      const uint16_t *l2 = klist + cstart[c2];
+      // kept lists are ascending in key (= descending score).  Entries of class c2 that precede (mykey, cls):
+      // key2 < mykey, or key2 == mykey and c2 < cls.
+      int lo = 0, hi = n2;
+      if (c2 < cls) {
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (key[l2[mid]] <= mykey) lo = mid + 1; else hi = mid;
+        }
+      } else {
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (key[l2[mid]] < mykey) lo = mid + 1; else hi = mid;
+        }
+      }
+      rank += lo;
+    }
+    if (rank < T) {
+      const int r = (int)(pk[slot] & 0xFFFFFFu);
+      float4 o = box_of(r, cls);
+      o.x = clip01(o.x);
+      o.y = clip01(o.y);
+      o.z = clip01(o.z);
+      o.w = clip01(o.w);
+      *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * T + rank) * 4) = o;
+      if (p.out_scores) p.out_scores[(long long)b * T + rank] = probs[(long long)r * L + cls];
+      if (p.out_labels) p.out_labels[(long long)b * T + rank] = (float)cls;
+    }
+  }
+  for (int r = nvalid + tid; r < T; r += kNT) {
+    *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * T + r) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.out_scores) p.out_scores[(long long)b * T + r] = 0.0f;
+    if (p.out_labels) p.out_labels[(long long)b * T + r] = 0.0f;
+  }
+  if (tid == 0 && p.out_valid) p.out_valid[b] = nvalid;
+}
+
+// *handled stays false when the fused kernel cannot hold the problem in LDS; the caller then takes the
+// generic sort -> NMS -> merge pipeline.
+int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
+                   int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
+                   float *out_scores, int *out_valid, hipStream_t stream, bool *handled) {
+  *handled = false;
+  if (L > kDecMaxClasses || R >= (1 << 24) || R <= 0 || max_total <= 0) return FRCNN_OK;
+  const long long rl = (long long)R * L;
+  if (rl > 65535) return FRCNN_OK;
+  const int Vcap = (int)((rl + 7) & ~7ll);
+  const int Rpc = max_total < R ? max_total : R;
+  const int Rpc4 = (Rpc + 3) & ~3;
+  int nms_waves = 8;
+  while (nms_waves > 1 && dec_lds_bytes(Vcap, Rpc4, nms_waves) > 160 * 1024) nms_waves >>= 1;
+  const size_t lds = dec_lds_bytes(Vcap, Rpc4, nms_waves);
+  if (lds > 160 * 1024) return FRCNN_OK;
+  DecoderParams p;
+  p.rois = rois;
+  p.deltas = deltas;
+  p.probs = probs;
+  p.v0 = variances[0];
+  p.v1 = variances[1];
+  p.v2 = variances[2];
+  p.v3 = variances[3];
+  p.R = R;
+  p.L = L;
+  p.T = max_total;
+  p.Rpc = Rpc;
+  p.score_thr = score_thr;
+  p.iou = make_iou_thr(iou_thr);
+  p.out_boxes = out_boxes;
+  p.out_labels = out_labels;
+  p.out_scores = out_scores;
+  p.out_valid = out_valid;
+  auto kern = decoder_kernel;
+  if (lds > 48 * 1024) {
+    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                       "decoder: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kNT), lds, stream, p, Vcap, Rpc4, nms_waves);
+  *handled = true;
+  return check_launch("decoder (fused kernel)");
+}
+
+}  // namespace frcnn

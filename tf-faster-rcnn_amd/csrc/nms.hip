@@ -354,6 +354,11 @@ int launch_proposal(const float *deltas, const float *scores, const float *ancho
                     int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
                     int *out_valid, hipStream_t stream, bool *handled);
 
+// decoder.hip
+int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
+                   int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
+                   float *out_scores, int *out_valid, hipStream_t stream, bool *handled);
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -470,6 +475,17 @@ int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
   FRCNN_REQUIRE(aligned_to(rois, 16) && aligned_to(deltas, 16) && aligned_to(out_boxes, 16),
                 "decoder: box pointers must be 16-byte aligned");
   if (B == 0) return FRCNN_OK;
+  {
+    // One fused kernel per image (decoder.hip) whenever its LDS budget allows; FRCNN_DECODER_UNFUSED=1 forces
+    // the generic sort -> NMS -> merge pipeline (used by the parity tests to cover both).
+    const char *force = getenv("FRCNN_DECODER_UNFUSED");
+    if (!(force && force[0] == '1')) {
+      bool handled = false;
+      int rc = launch_decoder(rois, deltas, probs, variances, B, R, L, max_total, score_threshold, iou_threshold,
+                              out_boxes, out_labels, out_scores, out_valid, (hipStream_t)stream, &handled);
+      if (rc || handled) return rc;
+    }
+  }
   ScoreSource ss;
   ss.scores = probs;
   ss.stride_b = (long long)R * L;

@@ -1,0 +1,134 @@
+"""Per-kernel timings against the HBM roofline (algorithmic bytes from SURVEY.md 8d / DESIGN.md).
+
+    python tools/bench_kernels.py [--only crop_cfg2,iou_map_cfg4,...] [--iters 50]
+
+Prints one JSON line per case: average launch time (HIP events on the launch stream), algorithmic GB/s
+and the fraction of the 8 TB/s HBM peak.  bench.py remains the contract benchmark; this is the per-kernel
+evidence (also the program profiled by the rocprofv3 --pmc passes, see profiles/).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import synth
+import tf_faster_rcnn_amd as pkg
+
+PEAK = 8000.0
+
+
+def timeit(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters  # ms
+
+
+def rois_for(B, G, K, R, seed=0, mode="inference"):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G, pre_nms_topn=K)
+    hp["train_nms_topn" if mode == "training" else "test_nms_topn"] = R
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    d, s = synth.rpn_outputs(seed, B, G)
+    layer = pkg.faster_rcnn.RoIBBox(anchors, mode, hp)
+    return hp, anchors, torch.as_tensor(d).cuda(), torch.as_tensor(s).cuda(), layer
+
+
+def case_crop(name, B, G, C, R, K, iters):
+    hp, anchors, d, s, layer = rois_for(B, G, K, R, mode="training")
+    rois = layer([d, s])
+    fm = torch.as_tensor(synth.feature_map(0, B, G, C)).cuda()
+    pool = pkg.faster_rcnn.RoIPooling(hp)
+    ms = timeit(lambda: pool([fm, rois]), iters)
+    nbytes = B * (R * 49 * C * 4 + G * G * C * 4 + R * 20)
+    return dict(case=name, kernel="crop_resize_kernel<4>", ms=ms, bytes=nbytes, B=B, R=R, C=C, G=G)
+
+
+def case_iou_map(name, B, G, M, iters):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G)
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    gt, _ = synth.gt_boxes(0, B, M)
+    gt = torch.as_tensor(gt).cuda()
+    ms = timeit(lambda: pkg.bbox_utils.generate_iou_map(anchors, gt), iters)
+    N = anchors.shape[0]
+    nbytes = B * (N * M * 4 + M * 16) + N * 16
+    return dict(case=name, kernel="iou_map_kernel<true>", ms=ms, bytes=nbytes, B=B, N=N, M=M)
+
+
+def case_targets(name, B, G, M, iters):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G)
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    N = anchors.shape[0]
+    gt, lab = synth.gt_boxes(0, B, M)
+    rp, rn = synth.sampling_ints(0, B, N)
+    gt, lab, rp, rn = (torch.as_tensor(a).cuda() for a in (gt, lab, rp, rn))
+    ms = timeit(lambda: pkg.train_utils.calculate_rpn_actual_outputs(anchors, gt, lab, hp, random_masks=(rp, rn)), iters)
+    nbytes = B * (M * 16 + M * 4 + N * 8 + N * 16 + N * 4) + N * 16  # fused: no map written (ALU bound, reported only)
+    return dict(case=name, kernel="iou_reduce_kernel + rpn_targets_kernel (fused path, no map)", ms=ms, bytes=nbytes, B=B, N=N, M=M,
+                images_per_s=B / (ms * 1e-3))
+
+
+def case_roi_bbox(name, B, G, K, R, iters, mode="inference"):
+    hp, anchors, d, s, layer = rois_for(B, G, K, R, mode=mode)
+    ms = timeit(lambda: layer([d, s]), iters)
+    N = anchors.shape[0]
+    return dict(case=name, kernel="proposal_kernel", ms=ms, bytes=B * (N * 4 + K * 16 + R * 16), B=B, N=N, K=K, R=R,
+                images_per_s=B / (ms * 1e-3))
+
+
+def case_decoder(name, B, R, L, iters):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    rng = np.random.default_rng(0)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    hd, hpb = synth.head_outputs(0, B, R, L)
+    rois, hd, hpb = (torch.as_tensor(a).cuda() for a in (rois, hd, hpb))
+    layer = pkg.faster_rcnn.Decoder(hp["variances"], L)
+    ms = timeit(lambda: layer([rois, hd, hpb]), iters)
+    return dict(case=name, kernel="decoder (sort + nms + merge)", ms=ms, bytes=B * (R * 16 + R * L * 20 + 200 * 24), B=B, R=R, L=L,
+                images_per_s=B / (ms * 1e-3))
+
+
+CASES = {
+    "crop_cfg2": lambda it: case_crop("crop_cfg2", 16, 32, 576, 300, 6000, it),
+    "crop_cfg3": lambda it: case_crop("crop_cfg3", 16, 31, 512, 2000, 6000, it),  # one GPU's shard of B=32 over 2 GPUs
+    "crop_cfg5": lambda it: case_crop("crop_cfg5", 16, 63, 576, 300, 12000, it),  # one GPU's shard of B=128 over 8
+    "iou_map_cfg4": lambda it: case_iou_map("iou_map_cfg4", 64, 32, 100, it),
+    "iou_map_cfg4_shard": lambda it: case_iou_map("iou_map_cfg4_shard", 8, 32, 100, it),
+    "targets_cfg4": lambda it: case_targets("targets_cfg4", 64, 32, 100, it),
+    "targets_cfg4_shard": lambda it: case_targets("targets_cfg4_shard", 8, 32, 100, it),
+    "roi_bbox_cfg2": lambda it: case_roi_bbox("roi_bbox_cfg2", 16, 32, 6000, 300, it),
+    "roi_bbox_cfg3": lambda it: case_roi_bbox("roi_bbox_cfg3", 16, 31, 6000, 2000, it, mode="training"),
+    "roi_bbox_cfg5": lambda it: case_roi_bbox("roi_bbox_cfg5", 16, 63, 12000, 300, it),
+    "decoder_cfg2": lambda it: case_decoder("decoder_cfg2", 16, 300, 21, it),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=50)
+    args = ap.parse_args()
+    names = [n for n in args.only.split(",") if n] or list(CASES)
+    for n in names:
+        r = CASES[n](args.iters)
+        gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+        r.update(ms=round(r["ms"], 5), GBps=round(gbs, 1), frac_of_8TBps=round(gbs / PEAK, 4))
+        if "images_per_s" in r:
+            r["images_per_s"] = round(r["images_per_s"], 1)
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
