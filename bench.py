@@ -43,6 +43,29 @@ def crop_bytes_per_image(cfg) -> int:
     return cfg["R"] * cfg["pool"] * cfg["pool"] * cfg["C"] * 4 + cfg["G"] * cfg["G"] * cfg["C"] * 4 + cfg["R"] * 20
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per crop launch from the committed rocprofv3 --pmc passes (profiles/r01_pmc_*): separate
+    FETCH_SIZE and WRITE_SIZE runs, KB units, FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B,
+    MI355X_MICROARCH.md section HBM).  None if the profiles are not there."""
+    import csv
+    import glob
+
+    def avg(pattern, counter):
+        vals = []
+        for path in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+            with open(path) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == counter and "crop_resize_kernel" in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+        return sum(vals) / len(vals) if vals else None
+
+    fetch = avg("r*_pmc_fetch_size_*.csv", "FETCH_SIZE")
+    write = avg("r*_pmc_write_size_*.csv", "WRITE_SIZE")
+    if fetch is None or write is None:
+        return None
+    return int((2.0 * fetch + write) * 1024)
+
+
 def make_inputs(cfg, seed):
     deltas, scores = synth.rpn_outputs(seed, cfg["B"], cfg["G"])
     fm = synth.feature_map(seed, cfg["B"], cfg["G"], cfg["C"])
@@ -173,7 +196,7 @@ def main() -> None:
                        "global_batch": cfg["B"] * world, "parallelism": f"dp{world} over images, no collectives"},
             "roofline": {"kernel": "crop_resize_kernel<4>", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
+                         "traffic": pmc_traffic_bytes(), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, inputs, hyper)
