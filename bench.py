@@ -34,6 +34,8 @@ import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
+TIME_EVERY = int(os.environ.get("FRCNN_BENCH_TIME_EVERY", "1"))  # pipeline mode: bracket every n-th crop launch with events
+
 # BASELINE config 2
 CFG = dict(backbone="mobilenet_v2", B=16, G=32, C=576, K=6000, R=300, L=21, pool=7)
 
@@ -108,9 +110,13 @@ def cpu_baseline(cfg, inputs, hyper, min_seconds=10.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=("pipeline", "sequential"), default="pipeline",
+                    help="pipeline: stages on three HIP streams, --depth batches in flight (tf_faster_rcnn_amd.pipeline); "
+                         "sequential: the three layers one after the other on one stream")
+    ap.add_argument("--depth", type=int, default=4)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,7 +147,7 @@ def main() -> None:
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
+    def step_sequential(i=None):
         rois = roi_bbox([deltas, scores])
         if i is not None:
             ev0[i].record()  # on the stream the kernel is launched on (torch's current stream)
@@ -151,27 +157,45 @@ def main() -> None:
         dets = decoder([rois, hd, hp])
         return pooled, dets
 
-    for _ in range(args.warmup):
-        step()
+    pipe = pkg.pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=args.depth)
+
+    def step_pipeline(i=None):
+        # every step is a full pass (RoIBBox -> RoIPooling -> Decoder) over its batch; the stages of up to
+        # --depth consecutive steps overlap on three streams.  The events bracket the crop kernel on ITS stream.
+        pipe.submit(deltas, scores, fm, (hd, hp), timing=None if (i is None or i % TIME_EVERY) else (ev0[i], ev1[i]))
 
     def barrier():
+        pipe.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(step_fn, record):
+        for _ in range(args.warmup):
+            step_fn()
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(args.steps):
+            step_fn(i if record else None)
+        barrier()
+        return time.perf_counter() - t_start
+
+    step = step_pipeline if args.mode == "pipeline" else step_sequential
+    elapsed = timed(step, True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    crop_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])) if args.steps else float("nan")
+    crop_ms = float(np.mean([a.elapsed_time(b) for i, (a, b) in enumerate(zip(ev0, ev1))
+                             if args.mode == "sequential" or i % TIME_EVERY == 0])) if args.steps else float("nan")
+    other = None
+    if world == 1:  # the other schedule, same K steps, reported beside the headline (not part of `value`)
+        other_elapsed = timed(step_sequential if args.mode == "pipeline" else step_pipeline, False)
+        other = {"mode": "sequential" if args.mode == "pipeline" else "pipeline",
+                 "value": round(cfg["B"] * args.steps / other_elapsed, 1),
+                 "ms_per_step": round(other_elapsed / args.steps * 1e3, 4)}
 
     if rank == 0:
         images = cfg["B"] * world * args.steps
@@ -193,11 +217,15 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: mobilenet_v2 RoI path, batch 16 per GPU, 500x500, 9216 anchors/img, "
                                    "pre_nms_topn 6000, post_nms 300, 7x7 crop_and_resize of 32x32x576, 21-label Decoder NMS",
-                       "global_batch": cfg["B"] * world, "parallelism": f"dp{world} over images, no collectives"},
+                       "global_batch": cfg["B"] * world, "parallelism": f"dp{world} over images, no collectives",
+                       "schedule": (f"stage pipeline on 3 HIP streams, {args.depth} batches in flight" if args.mode == "pipeline"
+                                    else "sequential on one stream")},
             "roofline": {"kernel": "crop_resize_kernel<4>", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic_bytes(), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
         }
+        if other is not None:
+            result["other_schedule"] = other
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(cfg, inputs, hyper)
         print(json.dumps(result), flush=True)

@@ -446,3 +446,49 @@ def test_rpn_targets(pkg, B, G, M):
     assert set(np.unique(l2)) <= {-1.0, 0.0, 1.0}
     nz = np.abs(d2.cpu().numpy()).sum(-1).reshape(B, -1) != 0
     assert (nz <= (l2 == 1)).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# stage pipeline over streams
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth,heads_callable", [(1, False), (3, False), (4, True)])
+def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable):
+    """Batches in flight on three streams give, per batch, exactly the sequential layers' (= the oracle's) results."""
+    from tf_faster_rcnn_amd import pipeline
+
+    B, G, C, L = 4, 16, 32, 6
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=1500, test_nms_topn=64, total_labels=L)
+    anchors = oracle.generate_anchors(hp)
+    roi_bbox = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)
+    roi_pool = pkg.faster_rcnn.RoIPooling(hp)
+    decoder = pkg.faster_rcnn.Decoder(hp["variances"], L)
+    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=depth)
+    batches = []
+    for seed in range(7):
+        deltas, scores = synth.rpn_outputs(seed, B, G)
+        fm = synth.feature_map(seed, B, G, C)
+        hd, hpb = synth.head_outputs(seed, B, 64, L)
+        batches.append((deltas, scores, fm, hd, hpb))
+    dev_batches = [tuple(dev(a) for a in b) for b in batches]
+    got = {}
+    for i, b in enumerate(dev_batches):
+        heads = (lambda pooled, rois, b=b: (b[3] + 0.0, b[4] + 0.0)) if heads_callable else (b[3], b[4])
+        t = pipe.submit(b[0], b[1], b[2], heads)
+        assert t == i
+        if i >= depth - 1:  # consume the oldest batch still in flight
+            j = i - (depth - 1)
+            got[j] = {k: v.clone() for k, v in pipe.result(j).items()}
+    for j in range(len(batches) - (depth - 1), len(batches)):
+        got[j] = {k: v.clone() for k, v in pipe.result(j, wait="stream").items()}
+    pipe.synchronize()
+    with pytest.raises(ValueError):
+        pipe.result(len(batches))
+    for i, b in enumerate(batches):
+        rois = oracle.roi_bbox(b[0], b[1], anchors, hp["variances"], 1500, 64, hp["nms_iou_threshold"])
+        pooled = oracle.roi_pooling(b[2], rois, hp["pooling_size"])
+        boxes, labels, sc = oracle.decoder(rois, b[3], b[4], hp["variances"], L)
+        seq = pipeline.run_sequential(roi_bbox, roi_pool, decoder, dev_batches[i])
+        for name, want in (("roi_bboxes", rois), ("roi_pooled", pooled), ("bboxes", boxes), ("labels", labels), ("scores", sc)):
+            assert_bits(got[i][name], want, f"pipeline batch {i} {name} vs oracle")
+            assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")

@@ -14,8 +14,15 @@
 //   - the 4 bilinear taps of an output pixel are 16 B-per-lane loads from the image's feature
 //     map, which stays resident in the XCD's 4 MiB L2: workgroups are remapped so that one XCD
 //     (blockIdx % 8) walks a contiguous range of boxes, i.e. one or two images at a time;
-//   - per-pixel sampling parameters (tap offsets, lerp weights) are computed once per box by the
-//     first ch*cw lanes and broadcast through LDS.
+//   - per-pixel sampling parameters (tap byte offsets, lerp weights) are computed once per box by the
+//     first ch*cw lanes and broadcast through LDS;
+//   - the inner loop is kept lean because the CU's vector-memory path is the co-limiter (4 tap loads + 1 store of
+//     16 B per lane = 2.78 GB per launch through 64 B/clk/CU; TA busy 75 % in profiles/r01_pmc_crop_*): SGPR-base +
+//     32-bit lane offsets (no 64-bit address arithmetic), packed fp32 lerps, 4 outputs (16 taps) in flight per lane
+//     at 4 waves per SIMD.
+//   Rejected after measurement (tools/crop_bench.hip): a (box, 256-B channel chunk) workgroup cuts L2 reads by 32 %
+//   through L1 reuse yet runs 12-20 % slower (more workgroups, same bytes through the vector-memory path); staging the
+//   unique taps in LDS caps the bytes in flight per CU below what the HBM stream needs.
 //
 // Numerics: the sampling coordinates and the three lerps are evaluated in exactly the TF
 // kernel's operation order, one rounding per operation (build has contraction off).
@@ -26,7 +33,7 @@ namespace frcnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct __attribute__((aligned(16))) PixParam {
-  int off_tl, off_tr, off_bl, off_br;  // tap offsets in units of VEC floats, relative to the image
+  unsigned off_tl, off_tr, off_bl, off_br;  // tap offsets in BYTES relative to the image (32-bit: host checks the size)
   float lx, ly;
   int valid;
   int pad;
@@ -43,8 +50,101 @@ struct VecT<1> {
   typedef float type;
 };
 
+// Sampling parameters of output pixel p of a box, in the TF kernel's operation order.
+__device__ __forceinline__ PixParam pix_param(int p, int H, int W, unsigned pix_bytes, int ch, int cw, float y1, float x1,
+                                              float y2, float x2, bool img_ok) {
+  const int y = p / cw;
+  const int x = p - y * cw;
+  const float hm1 = (float)(H - 1), wm1 = (float)(W - 1);
+  float in_y, in_x;
+  if (ch > 1) {
+    float t = y2 - y1;
+    t = t * hm1;
+    const float hs = t / (float)(ch - 1);
+    const float t0 = y1 * hm1;
+    const float t1 = (float)y * hs;
+    in_y = t0 + t1;
+  } else {
+    float t0 = y1 + y2;
+    t0 = 0.5f * t0;
+    in_y = t0 * hm1;
+  }
+  if (cw > 1) {
+    float t = x2 - x1;
+    t = t * wm1;
+    const float ws = t / (float)(cw - 1);
+    const float t0 = x1 * wm1;
+    const float t1 = (float)x * ws;
+    in_x = t0 + t1;
+  } else {
+    float t0 = x1 + x2;
+    t0 = 0.5f * t0;
+    in_x = t0 * wm1;
+  }
+  const bool ok = img_ok && (in_y >= 0.0f) && (in_y <= hm1) && (in_x >= 0.0f) && (in_x <= wm1);
+  PixParam prm;
+  if (ok) {
+    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
+    const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
+    prm.ly = in_y - (float)top;
+    prm.lx = in_x - (float)left;
+    prm.off_tl = (unsigned)(top * W + left) * pix_bytes;
+    prm.off_tr = (unsigned)(top * W + right) * pix_bytes;
+    prm.off_bl = (unsigned)(bot * W + left) * pix_bytes;
+    prm.off_br = (unsigned)(bot * W + right) * pix_bytes;
+    prm.valid = 1;
+  } else {
+    prm.ly = 0.0f;
+    prm.lx = 0.0f;
+    prm.off_tl = prm.off_tr = prm.off_bl = prm.off_br = 0;
+    prm.valid = 0;
+  }
+  prm.pad = 0;
+  return prm;
+}
+
+// a - b on the packed-fp32 pipe: v_pk_add_f32 with the neg modifier on b (exactly a - b); the compiler packs fadd/fmul of
+// <4 x float> but splits fsub into four v_sub_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vsub(float a, float b) { return a - b; }
+__device__ __forceinline__ f32x4 vsub(f32x4 a, f32x4 b) {
+  f32x2 lo, hi;
+  const f32x2 alo = a.xy, ahi = a.zw, blo = b.xy, bhi = b.zw;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(alo), "v"(blo));
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(ahi), "v"(bhi));
+  f32x4 r;
+  r.xy = lo;
+  r.zw = hi;
+  return r;
+}
+
+// One bilinear sample: three lerps, one rounding per operation.  `base` is wave-uniform and the lane offset 32-bit, so
+// the loads take the SGPR-base + VGPR-offset form (no 64-bit address arithmetic per tap); subtractions go through vsub (packed).
+template <class vec_t>
+__device__ __forceinline__ vec_t bilerp(const char *__restrict__ base, const PixParam &prm, unsigned cb, float extrap) {
+  const vec_t tl = *reinterpret_cast<const vec_t *>(base + (size_t)(prm.off_tl + cb));
+  const vec_t tr = *reinterpret_cast<const vec_t *>(base + (size_t)(prm.off_tr + cb));
+  const vec_t bl = *reinterpret_cast<const vec_t *>(base + (size_t)(prm.off_bl + cb));
+  const vec_t br = *reinterpret_cast<const vec_t *>(base + (size_t)(prm.off_br + cb));
+  vec_t t = vsub(tr, tl);
+  t = t * prm.lx;
+  const vec_t tp = tl + t;
+  t = vsub(br, bl);
+  t = t * prm.lx;
+  const vec_t bt = bl + t;
+  t = vsub(bt, tp);
+  t = t * prm.ly;
+  vec_t v = tp + t;
+  if (!prm.valid) v = (vec_t)(extrap);
+  return v;
+}
+
+#ifndef FRCNN_CROP_WAVES_PER_EU
+#define FRCNN_CROP_WAVES_PER_EU 4
+#endif
 template <int VEC>
-__global__ __launch_bounds__(256) void crop_resize_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRCNN_CROP_WAVES_PER_EU, FRCNN_CROP_WAVES_PER_EU)))
+void crop_resize_kernel(
     const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
     const int *__restrict__ box_ind, int n, int boxes_per_image, int ch, int cw, float extrap,
     float *__restrict__ out) {
@@ -75,94 +175,46 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(
   for (int p0 = 0; p0 < P; p0 += 256) {
     const int np = (P - p0 < 256) ? (P - p0) : 256;
     if (p0 > 0) __syncthreads();
-    if (tid < np) {
-      const int p = p0 + tid;
-      const int y = p / cw;
-      const int x = p - y * cw;
-      const float hm1 = (float)(H - 1), wm1 = (float)(W - 1);
-      float in_y, in_x;
-      if (ch > 1) {
-        float t = y2 - y1;
-        t = t * hm1;
-        const float hs = t / (float)(ch - 1);
-        const float t0 = y1 * hm1;
-        const float t1 = (float)y * hs;
-        in_y = t0 + t1;
-      } else {
-        float t0 = y1 + y2;
-        t0 = 0.5f * t0;
-        in_y = t0 * hm1;
-      }
-      if (cw > 1) {
-        float t = x2 - x1;
-        t = t * wm1;
-        const float ws = t / (float)(cw - 1);
-        const float t0 = x1 * wm1;
-        const float t1 = (float)x * ws;
-        in_x = t0 + t1;
-      } else {
-        float t0 = x1 + x2;
-        t0 = 0.5f * t0;
-        in_x = t0 * wm1;
-      }
-      const bool ok = img_ok && (in_y >= 0.0f) && (in_y <= hm1) && (in_x >= 0.0f) && (in_x <= wm1);
-      PixParam prm;
-      if (ok) {
-        const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
-        const int left = (int)floorf(in_x), right = (int)ceilf(in_x);
-        prm.ly = in_y - (float)top;
-        prm.lx = in_x - (float)left;
-        prm.off_tl = (top * W + left) * CV;
-        prm.off_tr = (top * W + right) * CV;
-        prm.off_bl = (bot * W + left) * CV;
-        prm.off_br = (bot * W + right) * CV;
-        prm.valid = 1;
-      } else {
-        prm.ly = 0.0f;
-        prm.lx = 0.0f;
-        prm.off_tl = prm.off_tr = prm.off_bl = prm.off_br = 0;
-        prm.valid = 0;
-      }
-      prm.pad = 0;
-      pp[tid] = prm;
-    }
+    if (tid < np) pp[tid] = pix_param(p0 + tid, H, W, (unsigned)C * 4u, ch, cw, y1, x1, y2, x2, img_ok);
     __syncthreads();
 
     const int total = np * CV;
-    vec_t *__restrict__ dst = reinterpret_cast<vec_t *>(out + ((long long)box * P + p0) * C);
+    const char *__restrict__ base = reinterpret_cast<const char *>(img);
+    char *__restrict__ dstb = reinterpret_cast<char *>(out + ((long long)box * P + p0) * C);
     int p = tid / CV;
     int c = tid - p * CV;
     const int dp = 256 / CV, dc = 256 - dp * CV;
 #ifndef FRCNN_CROP_UNROLL
 #define FRCNN_CROP_UNROLL 4
 #endif
-#pragma unroll FRCNN_CROP_UNROLL
-    for (int e = tid; e < total; e += 256) {
-      const PixParam prm = pp[p];
-      const vec_t tl = img[prm.off_tl + c];
-      const vec_t tr = img[prm.off_tr + c];
-      const vec_t bl = img[prm.off_bl + c];
-      const vec_t br = img[prm.off_br + c];
-      vec_t t = tr - tl;
-      t = t * prm.lx;
-      const vec_t tp = tl + t;
-      t = br - bl;
-      t = t * prm.lx;
-      const vec_t bt = bl + t;
-      t = bt - tp;
-      t = t * prm.ly;
-      vec_t v = tp + t;
-      if (!prm.valid) v = (vec_t)(extrap);
+    // FRCNN_CROP_UNROLL outputs per lane per trip, all their taps issued before the first lerp.  Unrolled by hand (the
+    // packed-subtract asm is convergent, which rules out the compiler's runtime unroll): lanes past the end recompute
+    // the last element (in-bounds loads) and skip the store.
+    for (int e0 = tid; e0 < total; e0 += 256 * FRCNN_CROP_UNROLL) {
+      vec_t v[FRCNN_CROP_UNROLL];
+#pragma unroll
+      for (int u = 0; u < FRCNN_CROP_UNROLL; ++u) {
+        const bool in = e0 + u * 256 < total;
+        const PixParam prm = pp[in ? p : 0];
+        v[u] = bilerp<vec_t>(base, prm, (unsigned)(in ? c : 0) * (unsigned)sizeof(vec_t), extrap);
+        c += dc;
+        p += dp;
+        if (c >= CV) {
+          c -= CV;
+          ++p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < FRCNN_CROP_UNROLL; ++u) {
+        const int e = e0 + u * 256;
+        if (e < total) {
+          vec_t *d = reinterpret_cast<vec_t *>(dstb + (size_t)((unsigned)e * (unsigned)sizeof(vec_t)));
 #ifdef FRCNN_CROP_PLAIN_STORE
-      dst[e] = v;
+          *d = v[u];
 #else
-      __builtin_nontemporal_store(v, &dst[e]);
+          __builtin_nontemporal_store(v[u], d);
 #endif
-      c += dc;
-      p += dp;
-      if (c >= CV) {
-        c -= CV;
-        ++p;
+        }
       }
     }
   }
@@ -182,7 +234,8 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   FRCNN_REQUIRE(crop_h > 0 && crop_w > 0, "crop_and_resize: crop size (%d,%d) must be positive", crop_h, crop_w);
   FRCNN_REQUIRE(n >= 0, "crop_and_resize: negative box count");
   FRCNN_REQUIRE(box_ind || boxes_per_image > 0, "crop_and_resize: box_ind is NULL and boxes_per_image <= 0");
-  FRCNN_REQUIRE((long long)H * W * C < (1ll << 31), "crop_and_resize: one image must hold fewer than 2^31 floats");
+  FRCNN_REQUIRE((long long)H * W * C < (1ll << 30), "crop_and_resize: one image must hold fewer than 2^30 floats");
+  FRCNN_REQUIRE(C < (1 << 20), "crop_and_resize: depth must be below 2^20");
   FRCNN_REQUIRE((long long)crop_h * crop_w < (1ll << 24), "crop_and_resize: crop too large");
   if (n == 0) return FRCNN_OK;
   const bool vec4 = (C % 4 == 0) && aligned_to(image, 16) && aligned_to(out, 16);

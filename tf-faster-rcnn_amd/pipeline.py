@@ -1,0 +1,206 @@
+"""Stage pipeline over HIP streams for the RoI path: RoIBBox | RoIPooling (+ heads) | Decoder.
+
+The proposal and Decoder kernels are latency bound (one workgroup per image: 16 of 256 CUs at batch
+16) while crop_and_resize is HBM-write bound and fills the chip.  Run one after the other on one
+stream they leave the GPU mostly idle for half of every step.  This runner keeps ``depth`` batches
+in flight: each stage owns a HIP stream, events carry the per-batch dependency
+``RoIBBox -> RoIPooling -> heads -> Decoder`` of the reference model (models/faster_rcnn.py:318-319,
+361-365), and the stages of consecutive batches overlap (batch i+1's proposals and batch i-1's
+Decoder run under batch i's crop).  Per batch the arithmetic, the kernels and the results are exactly
+those of the three layers called in sequence (tests/test_gpu_parity.py::test_pipeline_*).
+
+Host cost per batch is three C-ABI calls and a handful of event operations: outputs live in a ring of
+``depth`` preallocated slots, so nothing is allocated after the first batch of a given shape.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from .models.faster_rcnn import Decoder, RoIBBox, RoIPooling
+
+Heads = Union[Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
+              Tuple[torch.Tensor, torch.Tensor]]
+
+
+class _Slot:
+    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy")
+
+    def __init__(self) -> None:
+        self.rois = self.pooled = self.boxes = self.labels = self.scores = None
+        self.done = torch.cuda.Event()
+        self.inputs: Any = None
+        self.busy = False
+
+
+class RoIPathPipeline:
+    """``submit`` batches, ``result`` them in order (or out of order) within ``depth`` submissions.
+
+    Args:
+        roi_bbox, roi_pooling, decoder: the layers (same objects the sequential path uses).
+        depth: batches in flight = ring slots.  ``submit`` blocks the host once ``depth`` batches are
+            pending, so a slot's tensors stay valid until ``depth - 1`` further submissions.
+    """
+
+    def __init__(self, roi_bbox: RoIBBox, roi_pooling: RoIPooling, decoder: Decoder, depth: int = 4) -> None:
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        self.roi_bbox, self.roi_pooling, self.decoder = roi_bbox, roi_pooling, decoder
+        self.device = roi_bbox.anchors.device
+        if self.device.type != "cuda":
+            raise RuntimeError("RoIPathPipeline needs a ROCm GPU; there is no CPU fallback.")
+        self.depth = depth
+        with torch.cuda.device(self.device):
+            import os
+            prio = [int(v) for v in os.environ.get("FRCNN_PIPE_PRIO", "0,0,0").split(",")]
+            self.s_prop, self.s_pool, self.s_dec = (torch.cuda.Stream(self.device, priority=p) for p in prio)
+            self._skip_in = os.environ.get("FRCNN_PIPE_SKIP_IN") == "1"
+            self.slots: List[_Slot] = [_Slot() for _ in range(depth)]
+            self._ev_in = [torch.cuda.Event() for _ in range(depth)]
+            self._ev_rois = [torch.cuda.Event() for _ in range(depth)]
+            self._ev_heads = [torch.cuda.Event() for _ in range(depth)]
+        self._count = 0
+        self._shape_key: Optional[Tuple[int, ...]] = None
+        self._ws_prop: Optional[torch.Tensor] = None
+        self._ws_dec: Optional[torch.Tensor] = None
+        hp = roi_bbox.hyper_params
+        self._K = int(hp["pre_nms_topn"])
+        self._R = int(hp["train_nms_topn"] if roi_bbox.mode == "training" else hp["test_nms_topn"])
+        self._thr = float(hp["nms_iou_threshold"])
+        self._var_prop = _lib.float4(hp["variances"])
+        self._var_dec = _lib.float4(decoder.variances)
+        self._pool = tuple(int(v) for v in roi_pooling.hyper_params["pooling_size"])
+
+    # -- shape-dependent set-up, once per input shape ------------------------------------------------
+    def _prepare(self, deltas: torch.Tensor, scores: torch.Tensor, fm: torch.Tensor) -> None:
+        key = (deltas.shape[0], deltas.numel(), scores.numel()) + tuple(fm.shape)
+        if key == self._shape_key:
+            return
+        self.synchronize()
+        N = self.roi_bbox.anchors.shape[0]
+        B = deltas.shape[0]
+        if deltas.numel() != B * N * 4 or scores.numel() != B * N:
+            raise ValueError(f"rpn outputs {tuple(deltas.shape)} / {tuple(scores.shape)} do not match {N} anchors")
+        if fm.dim() != 4 or fm.shape[0] != B:
+            raise ValueError(f"feature_map must be ({B}, H, W, C), got {tuple(fm.shape)}")
+        lib = _lib.lib()
+        R, T, L = self._R, int(self.decoder.max_total_size), int(self.decoder.total_labels)
+        ph, pw = self._pool
+        dev, f32 = self.device, torch.float32
+        for s in self.slots:
+            s.rois = torch.empty((B, R, 4), dtype=f32, device=dev)
+            s.pooled = torch.empty((B, R, ph, pw, fm.shape[3]), dtype=f32, device=dev)
+            s.boxes = torch.empty((B, T, 4), dtype=f32, device=dev)
+            s.labels = torch.empty((B, T), dtype=f32, device=dev)
+            s.scores = torch.empty((B, T), dtype=f32, device=dev)
+        self._ws_prop = torch.empty(max(1, lib.frcnn_roi_bbox_workspace_bytes(B, N, self._K, R)), dtype=torch.uint8, device=dev)
+        self._ws_dec = torch.empty(max(1, lib.frcnn_decoder_workspace_bytes(B, R, L, T)), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        self._shape_key = key
+
+    # -- one batch ------------------------------------------------------------------------------------
+    def submit(self, rpn_bbox_deltas: torch.Tensor, rpn_labels: torch.Tensor, feature_map: torch.Tensor,
+               heads: Heads, timing: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None) -> int:
+        """Enqueue one batch; returns its ticket.
+
+        ``heads`` is either ``(pred_deltas (B,R,L*4), pred_label_probs (B,R,L))`` already on the device, or
+        a callable ``heads(pooled, rois) -> (pred_deltas, pred_label_probs)`` that is run on the pooling
+        stage's stream right after the crop (the dense heads of the model).  ``timing`` = two events
+        recorded immediately before and after the crop kernel on its stream.
+        """
+        lib = _lib.lib()
+        dev = self.device
+        deltas = _lib.device_tensor(rpn_bbox_deltas, torch.float32, dev)
+        scores = _lib.device_tensor(rpn_labels, torch.float32, dev)
+        fm = _lib.device_tensor(feature_map, torch.float32, dev)
+        self._prepare(deltas, scores, fm)
+        k = self._count % self.depth
+        slot = self.slots[k]
+        if slot.busy:
+            slot.done.synchronize()  # back-pressure; also makes dropping the old inputs safe
+        B, H, W, C = fm.shape
+        N = self.roi_bbox.anchors.shape[0]
+        R, T, L = self._R, int(self.decoder.max_total_size), int(self.decoder.total_labels)
+        s_prop, s_pool, s_dec = self.s_prop, self.s_pool, self.s_dec
+
+        ev_in = self._ev_in[k]
+        if not self._skip_in:
+            ev_in.record(torch.cuda.current_stream(dev))  # inputs were produced on the caller's stream
+            s_prop.wait_event(ev_in)
+        _lib.check(lib.frcnn_roi_bbox(deltas.data_ptr(), scores.data_ptr(), self.roi_bbox.anchors.data_ptr(),
+                                      self._var_prop, B, N, self._K, R, self._thr, slot.rois.data_ptr(), None, None,
+                                      self._ws_prop.data_ptr(), self._ws_prop.numel(), s_prop.cuda_stream))
+        ev_rois = self._ev_rois[k]
+        ev_rois.record(s_prop)
+
+        s_pool.wait_event(ev_rois)  # (ev_in is implied: the proposal stage waited for it)
+        if timing is not None:
+            timing[0].record(s_pool)
+        ph, pw = self._pool
+        _lib.check(lib.frcnn_crop_and_resize(fm.data_ptr(), B, H, W, C, slot.rois.data_ptr(), None, B * R, R, ph, pw,
+                                             0.0, slot.pooled.data_ptr(), s_pool.cuda_stream))
+        if timing is not None:
+            timing[1].record(s_pool)
+        if callable(heads):
+            with torch.cuda.stream(s_pool):
+                pred_deltas, pred_probs = heads(slot.pooled, slot.rois)
+        else:
+            pred_deltas, pred_probs = heads
+        pred_deltas = _lib.device_tensor(pred_deltas, torch.float32, dev)
+        pred_probs = _lib.device_tensor(pred_probs, torch.float32, dev)
+        if pred_deltas.numel() != B * R * L * 4 or tuple(pred_probs.shape) != (B, R, L):
+            raise ValueError(f"head outputs {tuple(pred_deltas.shape)} / {tuple(pred_probs.shape)} do not match "
+                             f"({B}, {R}, {L}*4) / ({B}, {R}, {L})")
+        ev_heads = self._ev_heads[k]
+        ev_heads.record(s_pool)
+
+        s_dec.wait_event(ev_heads)
+        _lib.check(lib.frcnn_decoder(slot.rois.data_ptr(), pred_deltas.data_ptr(), pred_probs.data_ptr(), self._var_dec,
+                                     B, R, L, T, float(self.decoder.score_threshold), 0.5, slot.boxes.data_ptr(),
+                                     slot.labels.data_ptr(), slot.scores.data_ptr(), None, self._ws_dec.data_ptr(),
+                                     self._ws_dec.numel(), s_dec.cuda_stream))
+        slot.done.record(s_dec)
+        slot.inputs = (deltas, scores, fm, pred_deltas, pred_probs)  # keep alive until the slot comes round again
+        slot.busy = True
+        ticket = self._count
+        self._count += 1
+        return ticket
+
+    def result(self, ticket: int, wait: str = "host") -> Dict[str, torch.Tensor]:
+        """Outputs of batch ``ticket``: ``roi_bboxes``, ``roi_pooled``, ``bboxes``, ``labels``, ``scores``.
+
+        ``wait="host"`` blocks until the batch is done; ``wait="stream"`` makes the caller's current stream
+        wait instead (no host block).  The tensors are ring slots: consume them before ``depth - 1`` further
+        ``submit`` calls."""
+        if not (self._count - self.depth <= ticket < self._count) or ticket < 0:
+            raise ValueError(f"ticket {ticket} is not in flight (last {self.depth} of {self._count} submissions are)")
+        slot = self.slots[ticket % self.depth]
+        if wait == "host":
+            slot.done.synchronize()
+        elif wait == "stream":
+            torch.cuda.current_stream(self.device).wait_event(slot.done)
+        else:
+            raise ValueError("wait must be 'host' or 'stream'")
+        return {"roi_bboxes": slot.rois, "roi_pooled": slot.pooled, "bboxes": slot.boxes, "labels": slot.labels,
+                "scores": slot.scores}
+
+    def synchronize(self) -> None:
+        """Block until every submitted batch is done."""
+        for s in self.slots:
+            if s.busy:
+                s.done.synchronize()
+                s.busy = False
+                s.inputs = None
+
+
+def run_sequential(roi_bbox: RoIBBox, roi_pooling: RoIPooling, decoder: Decoder,
+                   inputs: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The same batch through the three layers on the current stream (the reference's call order)."""
+    deltas, scores, fm, pred_deltas, pred_probs = inputs
+    rois = roi_bbox([deltas, scores])
+    pooled = roi_pooling([fm, rois])
+    boxes, labels, sc = decoder([rois, pred_deltas, pred_probs])
+    return {"roi_bboxes": rois, "roi_pooled": pooled, "bboxes": boxes, "labels": labels, "scores": sc}

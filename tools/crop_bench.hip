@@ -61,6 +61,54 @@ __global__ __launch_bounds__(T) void store_linear_kernel(f32x4 *out, long long n
   }
 }
 
+// variant: block = (crop, channel chunk of QC float4): 49 segments of QC*16 B strided by 2304 B; chunks of one crop are
+// consecutive blocks (optionally XCD-aware: consecutive crops stay on one XCD)
+template <int QC, bool XCD>
+__global__ __launch_bounds__(256) void store_chunk_kernel(f32x4 *out, int n, float v) {
+  const int nchunk = 144 / QC;
+  int bid = blockIdx.x;
+  int box, chunk;
+  if (XCD) {
+    const int grp = bid & 7, slot = bid >> 3;
+    const int q = n >> 3, r = n & 7;
+    const int start = (grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q;
+    box = start + slot / nchunk;
+    chunk = slot % nchunk;
+  } else {
+    box = bid / nchunk;
+    chunk = bid % nchunk;
+  }
+  f32x4 x = (f32x4)(v);
+  const int q = threadIdx.x % QC;
+  for (int p = threadIdx.x / QC; p < 49; p += 256 / QC) {
+    __builtin_nontemporal_store(x, &out[((long long)box * 49 + p) * 144 + chunk * QC + q]);
+  }
+}
+
+// variant: block = (crop, output row): 1008 contiguous float4
+template <bool NT>
+__global__ __launch_bounds__(256) void store_row_kernel(f32x4 *out, float v) {
+  f32x4 x = (f32x4)(v);
+  f32x4 *dst = out + (long long)blockIdx.x * 1008;
+  for (int e = threadIdx.x; e < 1008; e += 256) {
+    if (NT) __builtin_nontemporal_store(x, &dst[e]); else dst[e] = x;
+  }
+}
+
+// variant: tile of T*U float4 per block; each WAVE writes U consecutive KB (wave-contiguous), vs store_linear_kernel where
+// a wave's stores are T*16 B apart
+template <int T, int U, bool NT>
+__global__ __launch_bounds__(T) void store_wavecontig_kernel(f32x4 *out, long long n4, float v) {
+  f32x4 x = (f32x4)(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long long base = (long long)blockIdx.x * T * U + (long long)wave * 64 * U + lane;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    long long e = base + u * 64;
+    if (e < n4) { if (NT) __builtin_nontemporal_store(x, &out[e]); else out[e] = x; }
+  }
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <class F>
@@ -100,6 +148,7 @@ int main(int argc, char **argv) {
   float ms;
   ms = time_ms([&] { frcnn_crop_and_resize(img, B, H, W, C, boxes, nullptr, n, R, 7, 7, 0.f, out, nullptr); }, iters);
   printf("crop_and_resize (library)       %8.2f us  %7.1f GB/s algorithmic\n", ms * 1e3, alg / ms / 1e6);
+  if (argc > 1) return 0;  // quick mode: the library kernel only (PMC passes)
   ms = time_ms([&] { hipLaunchKernelGGL(store_kernel<true>, dim3(n), dim3(256), 0, 0, (f32x4 *)out, out_floats / 4, 1.f); }, iters);
   printf("store, block per crop, nt       %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
   ms = time_ms([&] { hipLaunchKernelGGL(store_kernel<false>, dim3(n), dim3(256), 0, 0, (f32x4 *)out, out_floats / 4, 1.f); }, iters);
@@ -128,6 +177,25 @@ int main(int argc, char **argv) {
     printf("store linear T256 x16           %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
     ms = time_ms([&] { hipLaunchKernelGGL((store_linear_kernel<1024, 4>), dim3((n4 + 4095) / 4096), dim3(1024), 0, 0, (f32x4 *)out, n4, 1.f); }, iters);
     printf("store linear T1024 x4           %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  }
+  ms = time_ms([&] { hipLaunchKernelGGL((store_chunk_kernel<16, false>), dim3(n * 9), dim3(256), 0, 0, (f32x4 *)out, n, 1.f); }, iters);
+  printf("store chunk 16q linear          %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_chunk_kernel<16, true>), dim3(n * 9), dim3(256), 0, 0, (f32x4 *)out, n, 1.f); }, iters);
+  printf("store chunk 16q xcd             %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_chunk_kernel<8, false>), dim3(n * 18), dim3(256), 0, 0, (f32x4 *)out, n, 1.f); }, iters);
+  printf("store chunk 8q linear           %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_chunk_kernel<48, false>), dim3(n * 3), dim3(256), 0, 0, (f32x4 *)out, n, 1.f); }, iters);
+  printf("store chunk 48q linear          %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_row_kernel<true>), dim3(n * 7), dim3(256), 0, 0, (f32x4 *)out, 1.f); }, iters);
+  printf("store row (16 KB) nt            %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_row_kernel<false>), dim3(n * 7), dim3(256), 0, 0, (f32x4 *)out, 1.f); }, iters);
+  printf("store row (16 KB) plain         %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  {
+    const long long n4 = out_floats / 4;
+#define WC(T, U, NT) ms = time_ms([&] { hipLaunchKernelGGL((store_wavecontig_kernel<T, U, NT>), dim3((n4 + T * U - 1) / (T * U)), dim3(T), 0, 0, (f32x4 *)out, n4, 1.f); }, iters); \
+    printf("store wave-contig T%d x%d nt=%d      %8.2f us  %7.1f GB/s\n", T, U, (int)NT, ms * 1e3, bytes / ms / 1e6);
+    WC(256, 1, false) WC(256, 1, true) WC(64, 1, false) WC(128, 1, false) WC(512, 1, false) WC(1024, 1, false)
+    WC(256, 2, false) WC(256, 4, false) WC(256, 4, true) WC(256, 8, false) WC(64, 4, false) WC(64, 16, false) WC(1024, 4, false)
   }
   ms = time_ms([&] { CK(hipMemsetAsync(out, 0, (size_t)bytes, 0)); }, iters);
   printf("hipMemsetAsync                  %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
