@@ -21,36 +21,73 @@ namespace frcnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // utils/bbox_utils.py:154-160 for one pair; barea/garea from :152-153.
-__device__ __forceinline__ float iou_pair(float by1, float bx1, float by2, float bx2, float barea,
-                                          float gy1, float gx1, float gy2, float gx2, float garea) {
-  float x_top = (bx1 > gx1) ? bx1 : gx1;
-  float y_top = (by1 > gy1) ? by1 : gy1;
-  float x_bot = (bx2 < gx2) ? bx2 : gx2;
-  float y_bot = (by2 < gy2) ? by2 : gy2;
+// NONAN: the caller has established that no coordinate of either box is NaN.  Then the reference's maximum / minimum
+// (written as the ternaries below, which is how they treat NaN) equal the hardware v_max_f32 / v_min_f32 up to the sign of
+// a zero, and a zero of either sign gives the same dx / dy after the clamp -- one instruction instead of two per min/max in
+// a kernel that sits on the VALU roof.
+template <bool NONAN>
+__device__ __forceinline__ void iou_terms(float by1, float bx1, float by2, float bx2, float barea, float gy1, float gx1,
+                                          float gy2, float gx2, float garea, float &inter, float &uni) {
+  float x_top, y_top, x_bot, y_bot;
+  if (NONAN) {
+    x_top = hw_max(bx1, gx1);
+    y_top = hw_max(by1, gy1);
+    x_bot = hw_min(bx2, gx2);
+    y_bot = hw_min(by2, gy2);
+  } else {
+    x_top = (bx1 > gx1) ? bx1 : gx1;
+    y_top = (by1 > gy1) ? by1 : gy1;
+    x_bot = (bx2 < gx2) ? bx2 : gx2;
+    y_bot = (by2 < gy2) ? by2 : gy2;
+  }
   float dx = x_bot - x_top;
   float dy = y_bot - y_top;
   dx = (dx > 0.0f) ? dx : 0.0f;
   dy = (dy > 0.0f) ? dy : 0.0f;
-  float inter = dx * dy;
-  float uni = barea + garea;
+  inter = dx * dy;
+  uni = barea + garea;
   uni = uni - inter;
+}
+
+template <bool NONAN>
+__device__ __forceinline__ float iou_pair(float by1, float bx1, float by2, float bx2, float barea,
+                                          float gy1, float gx1, float gy2, float gx2, float garea) {
+  float inter, uni;
+  iou_terms<NONAN>(by1, bx1, by2, bx2, barea, gy1, gx1, gy2, gx2, garea, inter, uni);
   return inter / uni;
 }
 
 // LDS layout (floats): gy1[Mp] gx1[Mp] gy2[Mp] gx2[Mp] garea[Mp], Mp = M rounded up to 4.
-__device__ __forceinline__ void stage_gt(float *lds, const float *__restrict__ gt, int M, int Mp) {
+// Returns (to every thread, after a barrier) whether any gt coordinate of the image is NaN: the area is NaN whenever a
+// coordinate is (it may also be NaN for infinite boxes, which merely selects the slower exact path).
+__device__ __forceinline__ bool stage_gt(float *lds, const float *__restrict__ gt, int M, int Mp) {
+  int nan = 0;
   for (int m = threadIdx.x; m < Mp; m += blockDim.x) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (m < M) g = *reinterpret_cast<const float4 *>(gt + (long long)m * 4);
     float gh = g.z - g.x;
     float gw = g.w - g.y;
+    const float ga = gh * gw;
     lds[m] = g.x;
     lds[Mp + m] = g.y;
     lds[2 * Mp + m] = g.z;
     lds[3 * Mp + m] = g.w;
-    lds[4 * Mp + m] = gh * gw;
+    lds[4 * Mp + m] = ga;
+    nan |= (ga != ga);
   }
+  return __syncthreads_or(nan) != 0;
 }
 
 // grid: (tiles, B).  Each block writes TILE_F4 consecutive float4 of image b's (N, M) slab.
@@ -62,19 +99,24 @@ __global__ __launch_bounds__(256) void iou_map_kernel(const float *__restrict__ 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int b = blockIdx.y;
   const int Mp = (M + 3) & ~3;
-  stage_gt(lds, gt + (long long)b * M * 4, M, Mp);
-  __syncthreads();
+  const bool gt_nan = stage_gt(lds, gt + (long long)b * M * 4, M, Mp);  // includes the barrier
   const float *bb = bboxes + (long long)b * bboxes_stride_b;
   float *ob = out + (long long)b * N * M;
+  // Index arithmetic is 32-bit and incremental (one division per lane per block, none per element): with the
+  // correctly rounded divide of every pair the kernel sits close to the VALU roof, so every instruction counts.
+  const unsigned W = VEC4 ? (unsigned)(M >> 2) : (unsigned)M;  // elements (float4 or float) per box row
+  const unsigned total = (unsigned)N * W;                      // < 2^31 (host-checked)
+  const unsigned e0 = blockIdx.x * (unsigned)per_block;
+  const unsigned e1 = (e0 + (unsigned)per_block < total) ? e0 + (unsigned)per_block : total;
+  unsigned e = e0 + threadIdx.x;
+  unsigned n = e / W;
+  unsigned m = e - n * W;
+  const unsigned dn = 256u / W, dm = 256u - dn * W;
   if (VEC4) {
-    const int M4 = M >> 2;
-    const long long total = (long long)N * M4;
-    const long long e0 = (long long)blockIdx.x * per_block;
-    const long long e1 = (e0 + per_block < total) ? e0 + per_block : total;
-    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
-      const int n = (int)(e / M4);
-      const int m0 = ((int)(e - (long long)n * M4)) << 2;
-      const float4 bx = *reinterpret_cast<const float4 *>(bb + (long long)n * 4);
+    f32x4 *__restrict__ o4 = reinterpret_cast<f32x4 *>(ob);
+    for (; e < e1; e += 256) {
+      const unsigned m0 = m << 2;
+      const float4 bx = *reinterpret_cast<const float4 *>(bb + (size_t)n * 4);
       const float bh = bx.z - bx.x;
       const float bw = bx.w - bx.y;
       const float barea = bh * bw;
@@ -84,26 +126,109 @@ __global__ __launch_bounds__(256) void iou_map_kernel(const float *__restrict__ 
       const f32x4 gx2 = *reinterpret_cast<const f32x4 *>(lds + 3 * Mp + m0);
       const f32x4 ga = *reinterpret_cast<const f32x4 *>(lds + 4 * Mp + m0);
       f32x4 v;
-      v.x = iou_pair(bx.x, bx.y, bx.z, bx.w, barea, gy1.x, gx1.x, gy2.x, gx2.x, ga.x);
-      v.y = iou_pair(bx.x, bx.y, bx.z, bx.w, barea, gy1.y, gx1.y, gy2.y, gx2.y, ga.y);
-      v.z = iou_pair(bx.x, bx.y, bx.z, bx.w, barea, gy1.z, gx1.z, gy2.z, gx2.z, ga.z);
-      v.w = iou_pair(bx.x, bx.y, bx.z, bx.w, barea, gy1.w, gx1.w, gy2.w, gx2.w, ga.w);
-      __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(ob) + e);
+      if (!gt_nan && __ballot(barea != barea) == 0ull) {  // wave-uniform: no NaN coordinate anywhere in this wave's pairs
+        v.x = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.x, gx1.x, gy2.x, gx2.x, ga.x);
+        v.y = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.y, gx1.y, gy2.y, gx2.y, ga.y);
+        v.z = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.z, gx1.z, gy2.z, gx2.z, ga.z);
+        v.w = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.w, gx1.w, gy2.w, gx2.w, ga.w);
+      } else {
+        v.x = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.x, gx1.x, gy2.x, gx2.x, ga.x);
+        v.y = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.y, gx1.y, gy2.y, gx2.y, ga.y);
+        v.z = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.z, gx1.z, gy2.z, gx2.z, ga.z);
+        v.w = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.w, gx1.w, gy2.w, gx2.w, ga.w);
+      }
+      __builtin_nontemporal_store(v, o4 + e);
+      n += dn;
+      m += dm;
+      if (m >= W) {
+        m -= W;
+        ++n;
+      }
     }
   } else {
-    const long long total = (long long)N * M;
-    const long long e0 = (long long)blockIdx.x * per_block;
-    const long long e1 = (e0 + per_block < total) ? e0 + per_block : total;
-    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
-      const int n = (int)(e / M);
-      const int m = (int)(e - (long long)n * M);
-      const float4 bx = *reinterpret_cast<const float4 *>(bb + (long long)n * 4);
+    for (; e < e1; e += 256) {
+      const float4 bx = *reinterpret_cast<const float4 *>(bb + (size_t)n * 4);
       const float bh = bx.z - bx.x;
       const float bw = bx.w - bx.y;
       const float barea = bh * bw;
-      ob[e] = iou_pair(bx.x, bx.y, bx.z, bx.w, barea, lds[m], lds[Mp + m], lds[2 * Mp + m],
-                       lds[3 * Mp + m], lds[4 * Mp + m]);
+      ob[e] = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, lds[m], lds[Mp + m], lds[2 * Mp + m], lds[3 * Mp + m],
+                              lds[4 * Mp + m]);
+      n += dn;
+      m += dm;
+      if (m >= W) {
+        m -= W;
+        ++n;
+      }
     }
+  }
+}
+
+// Materialised map, M % 4 == 0.  grid: (ceil(N/64), B), block 256.  A wave owns 16 consecutive boxes and walks their
+// rows four float4 (16 gts) at a time: lane l <-> (box l/4, float4 l%4 of the group), so four lanes write 64 contiguous
+// bytes and the box (load, area) is set up once per lane instead of once per element.
+//
+// The kernel is VALU bound (a correctly rounded divide is ~14 issue slots of the ~25 per pair), and most pairs of a real
+// batch do not intersect at all: zero-padded gt rows, and gts far from the 16 spatially adjacent anchors of a wave.  For
+// those the quotient is exactly +0 (inter == +0, union > 0), so a group in which NO lane has an intersection skips the
+// four divides (wave-uniform branch).
+__global__ __launch_bounds__(256) void iou_map_rows_kernel(const float *__restrict__ bboxes, long long bboxes_stride_b,
+                                                           const float *__restrict__ gt, int N, int M,
+                                                           float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y;
+  const int Mp = M;  // M % 4 == 0
+  const bool gt_nan = stage_gt(lds, gt + (long long)b * M * 4, M, Mp);  // includes the barrier
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + wave * 16 + (lane >> 2);
+  const int qsub = lane & 3;
+  const bool live = n < N;
+  float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) bx = *reinterpret_cast<const float4 *>(bboxes + (long long)b * bboxes_stride_b + (long long)n * 4);
+  const float bh = bx.z - bx.x;
+  const float bw = bx.w - bx.y;
+  const float barea = bh * bw;
+  const int W = M >> 2;
+  f32x4 *__restrict__ orow = reinterpret_cast<f32x4 *>(out + ((long long)b * N + (live ? n : 0)) * M);
+  // no NaN coordinate among this wave's boxes or the image's gts (a NaN coordinate makes the area NaN)
+  const bool nonan = !gt_nan && __ballot(barea != barea) == 0ull;
+  for (int q0 = 0; q0 < W; q0 += 4) {
+    const int q = q0 + qsub;
+    const bool ok = live && q < W;
+    const int m0 = (q < W ? q : W - 1) << 2;
+    const f32x4 gy1 = *reinterpret_cast<const f32x4 *>(lds + m0);
+    const f32x4 gx1 = *reinterpret_cast<const f32x4 *>(lds + Mp + m0);
+    const f32x4 gy2 = *reinterpret_cast<const f32x4 *>(lds + 2 * Mp + m0);
+    const f32x4 gx2 = *reinterpret_cast<const f32x4 *>(lds + 3 * Mp + m0);
+    const f32x4 ga = *reinterpret_cast<const f32x4 *>(lds + 4 * Mp + m0);
+    f32x4 v;
+    if (nonan) {
+      float in[4], un[4];
+      iou_terms<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.x, gx1.x, gy2.x, gx2.x, ga.x, in[0], un[0]);
+      iou_terms<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.y, gx1.y, gy2.y, gx2.y, ga.y, in[1], un[1]);
+      iou_terms<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.z, gx1.z, gy2.z, gx2.z, ga.z, in[2], un[2]);
+      iou_terms<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.w, gx1.w, gy2.w, gx2.w, ga.w, in[3], un[3]);
+      // every inter is >= +0 here (or NaN from inf * 0, which fails the test): their sum is 0 iff all four are
+      const float isum = (in[0] + in[1]) + (in[2] + in[3]);
+      const float umin = hw_min(hw_min(un[0], un[1]), hw_min(un[2], un[3]));
+      const bool trivial = (isum == 0.0f) && (umin > 0.0f);  // +0 / positive = +0 for all four
+      if (__ballot(ok && !trivial) == 0ull) {
+        v = (f32x4)(0.0f);
+      } else {
+        v.x = in[0] / un[0];
+        v.y = in[1] / un[1];
+        v.z = in[2] / un[2];
+        v.w = in[3] / un[3];
+      }
+    } else {
+      v.x = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.x, gx1.x, gy2.x, gx2.x, ga.x);
+      v.y = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.y, gx1.y, gy2.y, gx2.y, ga.y);
+      v.z = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.z, gx1.z, gy2.z, gx2.z, ga.z);
+      v.w = iou_pair<false>(bx.x, bx.y, bx.z, bx.w, barea, gy1.w, gx1.w, gy2.w, gx2.w, ga.w);
+    }
+    // plain (not nontemporal) store: the 64-B pieces of a line arrive in consecutive groups and merge in L2;
+    // nontemporal pieces go out as partial lines (3.6x slower), staging rows in LDS for full-line stores costs more
+    // issue slots than it saves (54-58 us against 49.5 at config 4)
+    if (ok) orow[q] = v;
   }
 }
 
@@ -115,6 +240,45 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = (o > v) ? o : v;
   }
   return v;
+}
+
+// One box against every gt of its image (row max / first argmax in registers, column keys merged in LDS).
+template <bool NONAN>
+__device__ __forceinline__ void reduce_row(const float *lds, int Mp, int M, float4 bx, float barea, bool live, int n,
+                                           bool want_cols, unsigned long long *colk, float &best, float &mx, int &am) {
+  const unsigned long long live_mask = __ballot(live);
+  for (int m = 0; m < M; ++m) {
+    float inter, uni;
+    iou_terms<NONAN>(bx.x, bx.y, bx.z, bx.w, barea, lds[m], lds[Mp + m], lds[2 * Mp + m], lds[3 * Mp + m], lds[4 * Mp + m],
+                     inter, uni);
+    // Zero-padded gts and gts far from this wave's 64 neighbouring boxes intersect none of them: the quotient is exactly
+    // +0 for every lane (inter == +0, union > 0), so the divide and the cross-lane maximum are skipped (wave-uniform).
+    const bool all_zero = NONAN && __ballot(live && !(inter == 0.0f && uni > 0.0f)) == 0ull;
+    const float v = all_zero ? 0.0f : inter / uni;
+    if (v > best) {
+      best = v;
+      am = m;
+    }
+    if (v > mx) mx = v;
+    if (want_cols) {
+      if (all_zero) {
+        // every live lane holds the same key: the lowest live lane (= smallest box index) reports it
+        if (live_mask != 0ull && lane_id() == (int)__builtin_ctzll(live_mask)) {
+          const unsigned long long key = ((unsigned long long)f_order_key(0.0f) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
+          atomicMax(&colk[m], key);
+        }
+        continue;
+      }
+      // key 0 = "no candidate" (dead lanes, NaN, and anything not above lowest()).
+      uint32_t k = (live && v > -3.402823466e+38f) ? f_order_key(v) : 0u;
+      const uint32_t wmax = wave_max_u32(k);
+      const unsigned long long hit = __ballot(k == wmax);
+      if (wmax != 0u && lane_id() == (int)__builtin_ctzll(hit)) {
+        const unsigned long long key = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
+        atomicMax(&colk[m], key);
+      }
+    }
+  }
 }
 
 // grid: (ceil(N/256), B); block 256: one box per lane.
@@ -129,10 +293,9 @@ __global__ __launch_bounds__(256) void iou_reduce_kernel(const float *__restrict
   const int b = blockIdx.y;
   const int Mp = (M + 3) & ~3;
   unsigned long long *colk = reinterpret_cast<unsigned long long *>(lds + 5 * Mp);
-  stage_gt(lds, gt + (long long)b * M * 4, M, Mp);
   if (col_keys)
     for (int m = threadIdx.x; m < M; m += 256) colk[m] = 0ull;
-  __syncthreads();
+  const bool gt_nan = stage_gt(lds, gt + (long long)b * M * 4, M, Mp);  // includes the barrier
 
   const int n = blockIdx.x * 256 + threadIdx.x;
   const bool live = n < N;
@@ -144,25 +307,10 @@ __global__ __launch_bounds__(256) void iou_reduce_kernel(const float *__restrict
   // [TF-recall] Eigen ArgMax / Max reducers: strict '>' starting from lowest().
   float best = -3.402823466e+38f, mx = -3.402823466e+38f;
   int am = 0;
-  for (int m = 0; m < M; ++m) {
-    const float v = iou_pair(bx.x, bx.y, bx.z, bx.w, barea, lds[m], lds[Mp + m], lds[2 * Mp + m],
-                             lds[3 * Mp + m], lds[4 * Mp + m]);
-    if (v > best) {
-      best = v;
-      am = m;
-    }
-    if (v > mx) mx = v;
-    if (col_keys) {
-      // key 0 = "no candidate" (dead lanes, NaN, and anything not above lowest()).
-      uint32_t k = (live && v > -3.402823466e+38f) ? f_order_key(v) : 0u;
-      const uint32_t wmax = wave_max_u32(k);
-      const unsigned long long hit = __ballot(k == wmax);
-      if (wmax != 0u && lane_id() == (int)__builtin_ctzll(hit)) {
-        const unsigned long long key = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
-        atomicMax(&colk[m], key);
-      }
-    }
-  }
+  if (!gt_nan && __ballot(barea != barea) == 0ull)  // wave-uniform: no NaN coordinate in this wave's boxes or the gts
+    reduce_row<true>(lds, Mp, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
+  else
+    reduce_row<false>(lds, Mp, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
   if (live) {
     if (max_iou) max_iou[(long long)b * N + n] = mx;
     if (argmax_row) argmax_row[(long long)b * N + n] = am;
@@ -203,16 +351,23 @@ int frcnn_iou_map(const float *bboxes, int bboxes_batched, const float *gt_boxes
   const size_t lds_bytes = (size_t)5 * Mp * sizeof(float);
   const bool vec4 = (M % 4 == 0) && aligned_to(out, 16);
   const long long total = vec4 ? (long long)N * (M / 4) : (long long)N * M;
-  // ~16 elements per lane per block keeps the grid well above 256 CUs x 8 at the reference sizes.
-  const int per_block = 256 * 16;
+  FRCNN_REQUIRE(total < (1ll << 31) - 65536, "iou_map: N*M per image too large");
+  // Small tiles written in address order stream best (tools/crop_bench.hip: 4-16 KB per workgroup); 8 elements per
+  // lane amortise the gt staging.  FRCNN_IOU_TILE overrides the per-lane count (diagnostic).
+  static const int per_lane = [] { const char *e = getenv("FRCNN_IOU_TILE"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+  const int per_block = 256 * per_lane;
   const long long tiles = (total + per_block - 1) / per_block;
-  FRCNN_REQUIRE(tiles < (1ll << 31), "iou_map: too large");
   dim3 grid((unsigned)tiles, (unsigned)B), block(256);
   const long long stride = bboxes_batched ? (long long)N * 4 : 0;
-  if (vec4)
-    hipLaunchKernelGGL(iou_map_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, bboxes, stride,
-                       gt_boxes, N, M, out, per_block);
-  else
+  if (vec4) {
+    static const bool flat = [] { const char *e = getenv("FRCNN_IOU_MAP_FLAT"); return e && atoi(e) != 0; }();  // diagnostic A/B
+    if (flat)
+      hipLaunchKernelGGL(iou_map_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, bboxes, stride, gt_boxes, N, M,
+                         out, per_block);
+    else
+      hipLaunchKernelGGL(iou_map_rows_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)B), block, lds_bytes,
+                         (hipStream_t)stream, bboxes, stride, gt_boxes, N, M, out);
+  } else
     hipLaunchKernelGGL(iou_map_kernel<false>, grid, block, lds_bytes, (hipStream_t)stream, bboxes, stride,
                        gt_boxes, N, M, out, per_block);
   return check_launch("iou_map");
