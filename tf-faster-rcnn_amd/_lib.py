@@ -140,3 +140,82 @@ def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Raw HIP events.  torch.cuda.Event cannot set AMD's release-scope flags: a default event performs a system-scope release
+# when it is recorded (an L2 write-back and invalidate behind every kernel it follows); events that only order one stream
+# of this GPU after another need a device-scope release.
+# ---------------------------------------------------------------------------------------------------------------------
+hipEventDefault = 0x0
+hipEventDisableTiming = 0x2
+hipEventDisableSystemFence = 0x20000000
+hipEventReleaseToDevice = 0x40000000
+
+_hip: Optional[ctypes.CDLL] = None
+
+
+def hip() -> ctypes.CDLL:
+    """The HIP runtime torch already loaded (same soname, so the same instance)."""
+    global _hip
+    if _hip is None:
+        handle = None
+        for name in ("libamdhip64.so.7", "libamdhip64.so"):
+            try:
+                handle = ctypes.CDLL(name)
+                break
+            except OSError:
+                continue
+        if handle is None:
+            raise RuntimeError("libamdhip64.so not found; a ROCm runtime is required (there is no CPU fallback)")
+        handle.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(_vp), ctypes.c_uint]
+        handle.hipEventDestroy.argtypes = [_vp]
+        handle.hipEventRecord.argtypes = [_vp, _vp]
+        handle.hipStreamWaitEvent.argtypes = [_vp, _vp, ctypes.c_uint]
+        handle.hipEventSynchronize.argtypes = [_vp]
+        handle.hipEventQuery.argtypes = [_vp]
+        handle.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), _vp, _vp]
+        handle.hipGetErrorString.restype = ctypes.c_char_p
+        handle.hipGetErrorString.argtypes = [ctypes.c_int]
+        _hip = handle
+    return _hip
+
+
+def _hip_check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what}: {hip().hipGetErrorString(rc).decode()} ({rc})")
+
+
+class HipEvent:
+    """hipEvent_t with explicit flags; the device current at construction owns it."""
+
+    __slots__ = ("handle", "_hip")
+
+    def __init__(self, flags: int = hipEventDisableTiming | hipEventReleaseToDevice) -> None:
+        self._hip = hip()
+        h = _vp()
+        _hip_check(self._hip.hipEventCreateWithFlags(ctypes.byref(h), flags), "hipEventCreateWithFlags")
+        self.handle = h
+
+    def record(self, stream: int) -> None:
+        _hip_check(self._hip.hipEventRecord(self.handle, stream), "hipEventRecord")
+
+    def wait(self, stream: int) -> None:
+        """Make ``stream`` wait for the most recent record of this event (no host block)."""
+        _hip_check(self._hip.hipStreamWaitEvent(stream, self.handle, 0), "hipStreamWaitEvent")
+
+    def synchronize(self) -> None:
+        _hip_check(self._hip.hipEventSynchronize(self.handle), "hipEventSynchronize")
+
+    def elapsed_time(self, end: "HipEvent") -> float:
+        """Milliseconds between this event and ``end`` (both created without hipEventDisableTiming, both complete)."""
+        ms = ctypes.c_float()
+        _hip_check(self._hip.hipEventElapsedTime(ctypes.byref(ms), self.handle, end.handle), "hipEventElapsedTime")
+        return float(ms.value)
+
+    def __del__(self) -> None:
+        try:
+            if self.handle:
+                self._hip.hipEventDestroy(self.handle)
+        except Exception:
+            pass

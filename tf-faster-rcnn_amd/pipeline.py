@@ -15,6 +15,7 @@ Host cost per batch is three C-ABI calls and a handful of event operations: outp
 
 from __future__ import annotations
 
+import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
@@ -31,7 +32,7 @@ class _Slot:
 
     def __init__(self) -> None:
         self.rois = self.pooled = self.boxes = self.labels = self.scores = None
-        self.done = torch.cuda.Event()
+        self.done = _lib.HipEvent(_lib.hipEventDisableTiming)  # host-visible: keeps the system-scope release
         self.inputs: Any = None
         self.busy = False
 
@@ -54,15 +55,14 @@ class RoIPathPipeline:
             raise RuntimeError("RoIPathPipeline needs a ROCm GPU; there is no CPU fallback.")
         self.depth = depth
         with torch.cuda.device(self.device):
-            import os
-            prio = [int(v) for v in os.environ.get("FRCNN_PIPE_PRIO", "0,0,0").split(",")]
-            self.s_prop, self.s_pool, self.s_dec = (torch.cuda.Stream(self.device, priority=p) for p in prio)
-            self._skip_in = os.environ.get("FRCNN_PIPE_SKIP_IN") == "1"
+            self.s_prop, self.s_pool, self.s_dec = (torch.cuda.Stream(self.device) for _ in range(3))
             self.slots: List[_Slot] = [_Slot() for _ in range(depth)]
-            self._ev_in = [torch.cuda.Event() for _ in range(depth)]
-            self._ev_rois = [torch.cuda.Event() for _ in range(depth)]
-            self._ev_heads = [torch.cuda.Event() for _ in range(depth)]
+            # stream-to-stream events: device-scope release (no L2 write-back behind the kernel they follow)
+            self._ev_in = [_lib.HipEvent() for _ in range(depth)]
+            self._ev_rois = [_lib.HipEvent() for _ in range(depth)]
+            self._ev_heads = [_lib.HipEvent() for _ in range(depth)]
         self._count = 0
+        self.wait_seconds = 0.0  # host time spent blocked on back-pressure (diagnostic)
         self._shape_key: Optional[Tuple[int, ...]] = None
         self._ws_prop: Optional[torch.Tensor] = None
         self._ws_dec: Optional[torch.Tensor] = None
@@ -103,13 +103,14 @@ class RoIPathPipeline:
 
     # -- one batch ------------------------------------------------------------------------------------
     def submit(self, rpn_bbox_deltas: torch.Tensor, rpn_labels: torch.Tensor, feature_map: torch.Tensor,
-               heads: Heads, timing: Optional[Tuple[torch.cuda.Event, torch.cuda.Event]] = None) -> int:
+               heads: Heads, timing: Optional[Tuple[Any, Any]] = None) -> int:
         """Enqueue one batch; returns its ticket.
 
         ``heads`` is either ``(pred_deltas (B,R,L*4), pred_label_probs (B,R,L))`` already on the device, or
         a callable ``heads(pooled, rois) -> (pred_deltas, pred_label_probs)`` that is run on the pooling
         stage's stream right after the crop (the dense heads of the model).  ``timing`` = two events
-        recorded immediately before and after the crop kernel on its stream.
+        (``_lib.HipEvent`` created with timing enabled; ``record(stream_handle)``) recorded immediately before and after
+        the crop kernel on its stream.
         """
         lib = _lib.lib()
         dev = self.device
@@ -120,30 +121,32 @@ class RoIPathPipeline:
         k = self._count % self.depth
         slot = self.slots[k]
         if slot.busy:
+            t_wait = time.perf_counter()
             slot.done.synchronize()  # back-pressure; also makes dropping the old inputs safe
+            self.wait_seconds += time.perf_counter() - t_wait
         B, H, W, C = fm.shape
         N = self.roi_bbox.anchors.shape[0]
         R, T, L = self._R, int(self.decoder.max_total_size), int(self.decoder.total_labels)
-        s_prop, s_pool, s_dec = self.s_prop, self.s_pool, self.s_dec
+        s_pool = self.s_pool
+        q_prop, q_pool, q_dec = self.s_prop.cuda_stream, self.s_pool.cuda_stream, self.s_dec.cuda_stream
 
         ev_in = self._ev_in[k]
-        if not self._skip_in:
-            ev_in.record(torch.cuda.current_stream(dev))  # inputs were produced on the caller's stream
-            s_prop.wait_event(ev_in)
+        ev_in.record(torch.cuda.current_stream(dev).cuda_stream)  # inputs were produced on the caller's stream
+        ev_in.wait(q_prop)
         _lib.check(lib.frcnn_roi_bbox(deltas.data_ptr(), scores.data_ptr(), self.roi_bbox.anchors.data_ptr(),
                                       self._var_prop, B, N, self._K, R, self._thr, slot.rois.data_ptr(), None, None,
-                                      self._ws_prop.data_ptr(), self._ws_prop.numel(), s_prop.cuda_stream))
+                                      self._ws_prop.data_ptr(), self._ws_prop.numel(), q_prop))
         ev_rois = self._ev_rois[k]
-        ev_rois.record(s_prop)
+        ev_rois.record(q_prop)
 
-        s_pool.wait_event(ev_rois)  # (ev_in is implied: the proposal stage waited for it)
+        ev_rois.wait(q_pool)  # (ev_in is implied: the proposal stage waited for it)
         if timing is not None:
-            timing[0].record(s_pool)
+            timing[0].record(q_pool)
         ph, pw = self._pool
         _lib.check(lib.frcnn_crop_and_resize(fm.data_ptr(), B, H, W, C, slot.rois.data_ptr(), None, B * R, R, ph, pw,
-                                             0.0, slot.pooled.data_ptr(), s_pool.cuda_stream))
+                                             0.0, slot.pooled.data_ptr(), q_pool))
         if timing is not None:
-            timing[1].record(s_pool)
+            timing[1].record(q_pool)
         if callable(heads):
             with torch.cuda.stream(s_pool):
                 pred_deltas, pred_probs = heads(slot.pooled, slot.rois)
@@ -155,14 +158,14 @@ class RoIPathPipeline:
             raise ValueError(f"head outputs {tuple(pred_deltas.shape)} / {tuple(pred_probs.shape)} do not match "
                              f"({B}, {R}, {L}*4) / ({B}, {R}, {L})")
         ev_heads = self._ev_heads[k]
-        ev_heads.record(s_pool)
+        ev_heads.record(q_pool)
 
-        s_dec.wait_event(ev_heads)
+        ev_heads.wait(q_dec)
         _lib.check(lib.frcnn_decoder(slot.rois.data_ptr(), pred_deltas.data_ptr(), pred_probs.data_ptr(), self._var_dec,
                                      B, R, L, T, float(self.decoder.score_threshold), 0.5, slot.boxes.data_ptr(),
                                      slot.labels.data_ptr(), slot.scores.data_ptr(), None, self._ws_dec.data_ptr(),
-                                     self._ws_dec.numel(), s_dec.cuda_stream))
-        slot.done.record(s_dec)
+                                     self._ws_dec.numel(), q_dec))
+        slot.done.record(q_dec)
         slot.inputs = (deltas, scores, fm, pred_deltas, pred_probs)  # keep alive until the slot comes round again
         slot.busy = True
         ticket = self._count
@@ -181,7 +184,7 @@ class RoIPathPipeline:
         if wait == "host":
             slot.done.synchronize()
         elif wait == "stream":
-            torch.cuda.current_stream(self.device).wait_event(slot.done)
+            slot.done.wait(torch.cuda.current_stream(self.device).cuda_stream)
         else:
             raise ValueError("wait must be 'host' or 'stream'")
         return {"roi_bboxes": slot.rois, "roi_pooled": slot.pooled, "bboxes": slot.boxes, "labels": slot.labels,
