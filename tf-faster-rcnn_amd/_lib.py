@@ -219,3 +219,4 @@ class HipEvent:
                 self._hip.hipEventDestroy(self.handle)
         except Exception:
             pass
+

@@ -52,6 +52,9 @@ __host__ __device__ static inline size_t dec_lds_bytes(int Vcap, int Rpc4, int n
 }
 
 __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
+  // One workgroup per image: latency bound.  When the stage pipeline runs it beside the chip-filling crop kernel, the
+  // crop's waves on this CU must not take its issue slots (they cost the crop 1/16 of its CUs, this kernel 40 %).
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // wave areas first (float4 alignment), then the 4-byte and 2-byte arrays
   unsigned char *wave_area = smem;

@@ -44,6 +44,9 @@ static inline size_t proposal_lds_bytes(int Rc, int S) {
 // passes and the compaction read LDS instead of re-reading the scores through L2.
 template <int CH>
 __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
+  // One workgroup per image: latency bound.  When the stage pipeline runs it beside the chip-filling crop kernel, the
+  // crop's waves on this CU must not take its issue slots (they cost the crop 1/16 of its CUs, this kernel 40 %).
+  __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const NmsLds<CH> L = carve_nms_lds<CH>(smem, Rc);
   unsigned char *q = smem + ((nms_lds_bytes<CH>(Rc) + 15) & ~(size_t)15);

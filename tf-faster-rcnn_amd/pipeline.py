@@ -9,12 +9,19 @@ in flight: each stage owns a HIP stream, events carry the per-batch dependency
 Decoder run under batch i's crop).  Per batch the arithmetic, the kernels and the results are exactly
 those of the three layers called in sequence (tests/test_gpu_parity.py::test_pipeline_*).
 
+Measured alternatives (BASELINE config 2, MI355X; ablations with FRCNN_PIPE_SKIP): the crop chain alone sustains 125 us
+per batch on one stream and 105 us when two streams alternate batches, but with the proposal and Decoder kernels present
+two crop lanes give no gain (136 us per batch either way: the single-workgroup kernels slow down under two overlapping
+crops and become the critical chain); confining them to reserved CUs with hipExtStreamCreateWithCUMask makes every
+cross-stream event wait cost ~200 us.  Hence one pooling stream.
+
 Host cost per batch is three C-ABI calls and a handful of event operations: outputs live in a ring of
 ``depth`` preallocated slots, so nothing is allocated after the first batch of a given shape.
 """
 
 from __future__ import annotations
 
+import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
@@ -62,6 +69,8 @@ class RoIPathPipeline:
             self._ev_rois = [_lib.HipEvent() for _ in range(depth)]
             self._ev_heads = [_lib.HipEvent() for _ in range(depth)]
         self._count = 0
+        # diagnostic ablation only (results are then wrong): FRCNN_PIPE_SKIP=prop,crop,dec leaves those launches out
+        self._skip = set(filter(None, os.environ.get("FRCNN_PIPE_SKIP", "").split(",")))
         self.wait_seconds = 0.0  # host time spent blocked on back-pressure (diagnostic)
         self._shape_key: Optional[Tuple[int, ...]] = None
         self._ws_prop: Optional[torch.Tensor] = None
@@ -133,7 +142,8 @@ class RoIPathPipeline:
         ev_in = self._ev_in[k]
         ev_in.record(torch.cuda.current_stream(dev).cuda_stream)  # inputs were produced on the caller's stream
         ev_in.wait(q_prop)
-        _lib.check(lib.frcnn_roi_bbox(deltas.data_ptr(), scores.data_ptr(), self.roi_bbox.anchors.data_ptr(),
+        if "prop" not in self._skip:
+          _lib.check(lib.frcnn_roi_bbox(deltas.data_ptr(), scores.data_ptr(), self.roi_bbox.anchors.data_ptr(),
                                       self._var_prop, B, N, self._K, R, self._thr, slot.rois.data_ptr(), None, None,
                                       self._ws_prop.data_ptr(), self._ws_prop.numel(), q_prop))
         ev_rois = self._ev_rois[k]
@@ -143,7 +153,8 @@ class RoIPathPipeline:
         if timing is not None:
             timing[0].record(q_pool)
         ph, pw = self._pool
-        _lib.check(lib.frcnn_crop_and_resize(fm.data_ptr(), B, H, W, C, slot.rois.data_ptr(), None, B * R, R, ph, pw,
+        if "crop" not in self._skip:
+          _lib.check(lib.frcnn_crop_and_resize(fm.data_ptr(), B, H, W, C, slot.rois.data_ptr(), None, B * R, R, ph, pw,
                                              0.0, slot.pooled.data_ptr(), q_pool))
         if timing is not None:
             timing[1].record(q_pool)
@@ -161,7 +172,8 @@ class RoIPathPipeline:
         ev_heads.record(q_pool)
 
         ev_heads.wait(q_dec)
-        _lib.check(lib.frcnn_decoder(slot.rois.data_ptr(), pred_deltas.data_ptr(), pred_probs.data_ptr(), self._var_dec,
+        if "dec" not in self._skip:
+          _lib.check(lib.frcnn_decoder(slot.rois.data_ptr(), pred_deltas.data_ptr(), pred_probs.data_ptr(), self._var_dec,
                                      B, R, L, T, float(self.decoder.score_threshold), 0.5, slot.boxes.data_ptr(),
                                      slot.labels.data_ptr(), slot.scores.data_ptr(), None, self._ws_dec.data_ptr(),
                                      self._ws_dec.numel(), q_dec))
