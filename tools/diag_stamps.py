@@ -35,3 +35,25 @@ for it in range(3):
         print("n stamps", n)
         for i in range(n):
             print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
+
+
+# ---- the same kernel while the crop kernel fills the chip on another stream (stage pipeline conditions) ----------
+# Workgroup 0's phases run at their stand-alone speed (82.6 us against 80.0): what the pipeline loses is RESIDENCY, not
+# speed -- a 1024-thread workgroup with ~100 VGPRs needs a CU empty of crop waves and only finds one in a crop launch's tail.
+fm = torch.as_tensor(synth.feature_map(0, 16, 32, 576)).cuda()
+pool = pkg.faster_rcnn.RoIPooling(hp)
+rois = layer([d, s])
+sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+torch.cuda.synchronize()
+lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+with torch.cuda.stream(sa):
+    for _ in range(4):
+        pool([fm, rois])
+with torch.cuda.stream(sb):
+    layer([d, s])
+torch.cuda.synchronize()
+n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+print("---- beside 4 crop launches on another stream ----")
+for i in range(n):
+    print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
