@@ -144,6 +144,19 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
                       float *out_deltas, float *out_labels, void *workspace,
                       size_t workspace_bytes, frcnn_stream_t stream);
 
+/* models/faster_rcnn.py:195-235 RoIDelta.call (second-stage training targets): RoI x gt IoU (:215), row max /
+ * first argmax (:216-217), positives > 0.5 and negatives in (0.1, 0.5) sub-sampled to total_pos / total_neg
+ * (:218-221), gathered gt box / label (:222-229), encode / variances (:230), one-hot labels and the per-class
+ * delta "scatter" (:231-234).  rois (B,R,4); gt_boxes (B,M,4), M >= 1; gt_labels (B,M) int32.  rnd_pos / rnd_neg:
+ * (B,R) int32 random integers of the two sampling calls, or both NULL to draw them in-kernel from `seed`.
+ * out_deltas (B,R*L,4); out_labels (B,R,L) one-hot fp32. */
+size_t frcnn_roi_delta_workspace_bytes(int B, int R, int M);
+int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_labels,
+                    const int32_t *rnd_pos, const int32_t *rnd_neg, uint64_t seed, int B, int R,
+                    int M, int total_labels, int total_pos, int total_neg, const float *variances,
+                    float *out_deltas, float *out_labels, void *workspace, size_t workspace_bytes,
+                    frcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

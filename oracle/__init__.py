@@ -289,3 +289,23 @@ def calculate_rpn_actual_outputs(anchors, gt_boxes, gt_labels, hyper_params, ran
     if debug:
         return od, labels, dm, dr, dc[:, :M]
     return od, labels
+
+
+def roi_delta(roi_bboxes, gt_boxes, gt_labels, hyper_params, random_masks):
+    """models/faster_rcnn.py:206-235 (RoIDelta.call).  ``random_masks = (pos, neg)``: the (B,R) int32 random integers of
+    the two ``randomly_select_xyz_mask`` calls.  Returns ``(roi_bbox_deltas (B,R*L,4), roi_bbox_labels (B,R,L))``."""
+    rois, gt_boxes, gt_labels = _f32(roi_bboxes), _f32(gt_boxes), _i32(gt_labels)
+    rp, rn = _i32(random_masks[0]), _i32(random_masks[1])
+    B, R = rois.shape[0], rois.shape[1]
+    M = gt_boxes.shape[1]
+    if M < 1:
+        raise ValueError("RoIDelta needs at least one (possibly padded) gt box per image")
+    L = int(hyper_params["total_labels"])
+    var = _f32(hyper_params["variances"])
+    od = np.empty((B, R * L, 4), dtype=np.float32)
+    ol = np.empty((B, R, L), dtype=np.float32)
+    lib().orc_roi_delta(_p(rois, _f32p), _p(gt_boxes, _f32p), _p(gt_labels, _i32p), _p(rp, _i32p), _p(rn, _i32p),
+                        ctypes.c_int(B), ctypes.c_int(R), ctypes.c_int(M), ctypes.c_int(L),
+                        ctypes.c_int(int(hyper_params["total_pos_bboxes"])), ctypes.c_int(int(hyper_params["total_neg_bboxes"])),
+                        _p(var, _f32p), _p(od, _f32p), _p(ol, _f32p))
+    return od, ol

@@ -810,3 +810,69 @@ void orc_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t 
     free(iou);
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * RoIDelta -- models/faster_rcnn.py:206-235 (second-stage training targets).
+ * roi_bboxes (B,R,4); gt_boxes (B,M,4); gt_labels (B,M) int32; rnd_pos / rnd_neg (B,R) int32 are the
+ * random integers of the two randomly_select_xyz_mask calls (:219, :221; utils/train_utils.py:82-83).
+ * out_deltas (B, R*L, 4); out_labels (B,R,L) one-hot fp32.
+ * ---------------------------------------------------------------------------------------- */
+void orc_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_labels,
+                   const int32_t *rnd_pos, const int32_t *rnd_neg, int B, int R, int M, int L,
+                   int total_pos, int total_neg, const float *variances, float *out_deltas,
+                   float *out_labels) {
+  int b;
+#pragma omp parallel for num_threads(g_threads) if (g_threads > 1)
+  for (b = 0; b < B; ++b) {
+    float *iou = (float *)malloc(sizeof(float) * (size_t)(R > 0 ? R : 1) * (M > 0 ? M : 1));
+    float *maxiou = (float *)malloc(sizeof(float) * (size_t)(R > 0 ? R : 1));
+    int32_t *arow = (int32_t *)malloc(sizeof(int32_t) * (size_t)(R > 0 ? R : 1));
+    uint8_t *pos = (uint8_t *)malloc((size_t)(R > 0 ? R : 1));
+    uint8_t *pos_sel = (uint8_t *)malloc((size_t)(R > 0 ? R : 1));
+    uint8_t *neg = (uint8_t *)malloc((size_t)(R > 0 ? R : 1));
+    uint8_t *neg_sel = (uint8_t *)malloc((size_t)(R > 0 ? R : 1));
+    const float *g = gt_boxes + (size_t)b * M * 4;
+    const float *rb = rois + (size_t)b * R * 4;
+    int r, m, l, c;
+    orc_iou_map(rb, 0, g, 1, R, M, iou); /* :215 (this image's slice; bboxes are per image here) */
+    for (r = 0; r < R; ++r) {            /* :216-217  [TF-recall] first maximal index, strict > from lowest(); NaN never wins */
+      float best = -FLT_MAX, mx = -FLT_MAX;
+      int am = 0;
+      for (m = 0; m < M; ++m) {
+        float v = iou[(size_t)r * M + m];
+        if (v > best) {
+          best = v;
+          am = m;
+        }
+        if (v > mx) mx = v;
+      }
+      arow[r] = am;
+      maxiou[r] = mx;
+    }
+    for (r = 0; r < R; ++r) pos[r] = (uint8_t)(maxiou[r] > 0.5f);                      /* :218 */
+    select_row(pos, rnd_pos + (size_t)b * R, total_pos, R, pos_sel);                   /* :219 */
+    for (r = 0; r < R; ++r) neg[r] = (uint8_t)((maxiou[r] < 0.5f) && (maxiou[r] > 0.1f)); /* :220 */
+    select_row(neg, rnd_neg + (size_t)b * R, total_neg, R, neg_sel);                   /* :221 */
+    for (r = 0; r < R; ++r) {
+      float gsel[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      float d[4];
+      int32_t lab;
+      if (pos_sel[r]) memcpy(gsel, g + (size_t)arow[r] * 4, 16);                         /* :222-223 */
+      lab = (pos_sel[r] ? gt_labels[(size_t)b * M + arow[r]] : -1) + (neg_sel[r] ? 1 : 0); /* :224-229 */
+      encode_one(rb + (size_t)r * 4, gsel, variances, d);                               /* :230 */
+      for (l = 0; l < L; ++l) {
+        float oh = (lab == l) ? 1.0f : 0.0f; /* :231 one_hot: out-of-range labels give an all-zero row */
+        out_labels[((size_t)b * R + r) * L + l] = oh;
+        for (c = 0; c < 4; ++c) /* :232-234 the scatter is a multiply: 0 * delta keeps delta's sign / NaN */
+          out_deltas[(((size_t)b * R + r) * L + l) * 4 + c] = oh * d[c];
+      }
+    }
+    free(neg_sel);
+    free(neg);
+    free(pos_sel);
+    free(pos);
+    free(arow);
+    free(maxiou);
+    free(iou);
+  }
+}

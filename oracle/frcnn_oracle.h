@@ -105,6 +105,14 @@ void orc_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t 
                      float *out_labels, float *dbg_max_iou, int32_t *dbg_argmax_row,
                      int32_t *dbg_argmax_col);
 
+/* models/faster_rcnn.py:206-235 (RoIDelta.call).  rois (B,R,4); gt_boxes (B,M,4), M >= 1; gt_labels (B,M) int32;
+ * rnd_pos / rnd_neg (B,R) int32: the random integers of the two sampling calls.
+ * out_deltas (B,R*L,4); out_labels (B,R,L) one-hot fp32. */
+void orc_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_labels,
+                   const int32_t *rnd_pos, const int32_t *rnd_neg, int B, int R, int M, int L,
+                   int total_pos, int total_neg, const float *variances, float *out_deltas,
+                   float *out_labels);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,6 +39,18 @@ def main() -> None:
     np.savez_compressed(os.path.join(HERE, "rpn_targets.npz"), anchors=anchors, gt_boxes=gt, gt_labels=labels, rnd_pos=rp,
                         rnd_neg=rn, iou_map=iou, max_iou=miou, argmax_row=arow, argmax_col=acol, bbox_deltas=tdel,
                         bbox_labels=tlab)
+    # RoIDelta: RoIs = the proposals above plus jittered copies of the gts (so positives and negatives exist)
+    Lr, Rr = 5, 24
+    rng = np.random.default_rng(3)
+    rd_rois = np.concatenate([rois, np.clip(np.repeat(gt, 2, axis=1) + rng.normal(0, 0.05, (B, 2 * M, 4)), 0, 1)], 1).astype(np.float32)
+    rd_rois[:, Rr - 2:] = 0.0
+    rd_lab = np.where(labels >= 0, labels % (Lr - 1) + 1, labels).astype(np.int32)
+    rdp = rng.integers(1, 40, (B, Rr), dtype=np.int32)
+    rdn = rng.integers(1, 40, (B, Rr), dtype=np.int32)
+    hp_r = dict(hp, total_labels=Lr, total_pos_bboxes=4, total_neg_bboxes=4)
+    rdd, rdl = oracle.roi_delta(rd_rois, gt, rd_lab, hp_r, (rdp, rdn))
+    np.savez_compressed(os.path.join(HERE, "roi_delta.npz"), rois=rd_rois, gt_boxes=gt, gt_labels=rd_lab, rnd_pos=rdp,
+                        rnd_neg=rdn, roi_bbox_deltas=rdd, roi_bbox_labels=rdl)
     print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
 
 

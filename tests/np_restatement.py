@@ -175,3 +175,56 @@ def single_class_nms(boxes, scores, max_out, iou_thr, score_thr=-np.inf):
         if all(not (nms_iou(boxes[i], boxes[j]) > f32(iou_thr)) for j in reversed(sel)):
             sel.append(i)
     return sel
+
+
+def get_deltas_from_bboxes(bboxes, gt):
+    """utils/bbox_utils.py:121-135, vectorised like the reference (tf.where selects after computing both sides)."""
+    b, g = np.asarray(bboxes, f32), np.asarray(gt, f32)
+    bw = b[..., 3] - b[..., 1]
+    bh = b[..., 2] - b[..., 0]
+    bcx = b[..., 1] + f32(0.5) * bw
+    bcy = b[..., 0] + f32(0.5) * bh
+    gw = g[..., 3] - g[..., 1]
+    gh = g[..., 2] - g[..., 0]
+    gcx = g[..., 1] + f32(0.5) * gw
+    gcy = g[..., 0] + f32(0.5) * gh
+    bw = np.where(bw == 0, f32(1e-3), bw)
+    bh = np.where(bh == 0, f32(1e-3), bh)
+    with np.errstate(all="ignore"):
+        dx = np.where(gw == 0, f32(0), (gcx - bcx) / bw)
+        dy = np.where(gh == 0, f32(0), (gcy - bcy) / bh)
+        dw = np.where(gw == 0, f32(0), cephes_log(np.where(gw == 0, f32(1), gw / bw)))
+        dh = np.where(gh == 0, f32(0), cephes_log(np.where(gh == 0, f32(1), gh / bh)))
+    return np.stack([dy, dx, dh, dw], axis=-1).astype(f32)
+
+
+def randomly_select_xyz_mask(mask, select, rnd):
+    """utils/train_utils.py:82-88 with the random integers given: double argsort, descending, ties by lower index."""
+    mask = np.asarray(mask, bool)
+    key = mask.astype(np.int32) * np.asarray(rnd, np.int32)
+    order = np.argsort(-key.astype(np.int64), axis=-1, kind="stable")
+    ranks = np.argsort(order, axis=-1, kind="stable")
+    sel = np.asarray(select).reshape(-1, 1)
+    return mask & (ranks < sel)
+
+
+def roi_delta(rois, gt, labels, total_labels, total_pos, total_neg, variances, rnd_pos, rnd_neg):
+    """models/faster_rcnn.py:215-234, op for op (positive, NaN-free gt coordinates only: np.maximum propagates NaN)."""
+    rois, gt, labels = np.asarray(rois, f32), np.asarray(gt, f32), np.asarray(labels, np.int32)
+    iou = generate_iou_map(rois, gt)
+    # [TF-recall] argmax / reduce_max skip NaN (strict > from lowest())
+    filled = np.where(np.isnan(iou), -np.inf, iou)
+    arg = np.argmax(filled, axis=2)
+    merged = np.where(np.isinf(filled.max(axis=2)), f32(-3.402823466e38), filled.max(axis=2)).astype(f32)
+    pos = randomly_select_xyz_mask(merged > f32(0.5), [total_pos], rnd_pos)
+    neg = randomly_select_xyz_mask((merged < f32(0.5)) & (merged > f32(0.1)), [total_neg], rnd_neg)
+    gmap = np.take_along_axis(gt, arg[..., None], axis=1)
+    egt = np.where(pos[..., None], gmap, f32(0))
+    lmap = np.take_along_axis(labels, arg, axis=1)
+    elab = np.where(pos, lmap, -1) + neg.astype(np.int32)
+    d = (get_deltas_from_bboxes(rois, egt) / np.asarray(variances, f32)).astype(f32)
+    onehot = (elab[..., None] == np.arange(total_labels)).astype(f32)
+    with np.errstate(invalid="ignore"):
+        out = onehot[..., None] * d[..., None, :]
+    B, R = rois.shape[:2]
+    return out.reshape(B, R * total_labels, 4).astype(f32), onehot

@@ -449,6 +449,61 @@ def test_rpn_targets(pkg, B, G, M):
 
 
 # ------------------------------------------------------------------------------------------------
+# RoIDelta (second-stage training targets)
+# ------------------------------------------------------------------------------------------------
+def _roi_delta_case(seed, B, R, M, L, G=16):
+    """RoIs near the gts (so that positives exist), zero-padded RoI rows, padded gts."""
+    rng = np.random.default_rng(seed)
+    gt, labels = synth.gt_boxes(seed, B, M)
+    labels = np.where(labels >= 0, labels % max(L - 1, 1) + 1, labels).astype(np.int32)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    for b in range(B):  # a third of the RoIs are jittered copies of valid gts -> IoU > 0.5 / in (0.1, 0.5)
+        valid = np.flatnonzero(labels[b] >= 0)
+        if len(valid):
+            pick = rng.choice(valid, R // 3)
+            jit = rng.normal(0, 0.04, (R // 3, 4)).astype(np.float32)
+            rois[b, : R // 3] = np.clip(gt[b, pick] + jit, 0, 1)
+    rois[:, -5:] = 0.0  # NMS padding rows: IoU with padded gts is 0/0 = NaN
+    return rois, gt, labels
+
+
+@pytest.mark.parametrize("B,R,M,L,pos,neg", [(2, 64, 4, 5, 8, 8), (4, 1500, 100, 21, 128, 128), (3, 300, 17, 21, 128, 128),
+                                             (2, 2000, 8, 21, 0, 3000)])
+def test_roi_delta(pkg, B, R, M, L, pos, neg):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(total_labels=L, total_pos_bboxes=pos, total_neg_bboxes=neg)
+    rois, gt, labels = _roi_delta_case(R + M, B, R, M, L)
+    rng = np.random.default_rng(5)
+    rp = rng.integers(1, max(10 * pos, 2), (B, R), dtype=np.int32)
+    rn = rng.integers(1, max(10 * neg, 2), (B, R), dtype=np.int32)
+    layer = pkg.faster_rcnn.RoIDelta(hp, name="roi_deltas")
+    got_d, got_l = layer([dev(rois), dev(gt), dev(labels)], random_masks=(dev(rp), dev(rn)))
+    want_d, want_l = oracle.roi_delta(rois, gt, labels, hp, (rp, rn))
+    assert want_l.sum() > 0  # the case exercises positives / negatives
+    assert_bits(got_l, want_l, "RoIDelta labels")
+    assert_bits(got_d, want_d, "RoIDelta deltas")
+    # in-kernel draw: structural properties
+    d2, l2 = layer([dev(rois), dev(gt), dev(labels)], seed=11)
+    l2 = l2.cpu().numpy()
+    assert set(np.unique(l2)) <= {0.0, 1.0} and (l2.sum(-1) <= 1).all()
+    assert (l2[..., 1:].sum((1, 2)) <= pos).all() and (l2[..., 0].sum(1) <= neg).all()
+    nz = np.abs(d2.cpu().numpy()).reshape(B, R, L, 4).sum(-1) != 0
+    assert (nz <= (l2 == 1)).all()
+
+
+def test_roi_delta_errors(pkg):
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(total_labels=5)
+    layer = pkg.faster_rcnn.RoIDelta(hp)
+    rois = dev(np.zeros((2, 8, 4), np.float32))
+    with pytest.raises(ValueError):
+        layer([rois, dev(np.zeros((2, 0, 4), np.float32)), dev(np.zeros((2, 0), np.int32))])
+    with pytest.raises(ValueError):
+        layer([rois, dev(np.zeros((3, 4, 4), np.float32)), dev(np.zeros((3, 4), np.int32))])
+    assert layer.get_config()["hyper_params"] is hp
+
+
+# ------------------------------------------------------------------------------------------------
 # stage pipeline over streams
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("depth,heads_callable", [(1, False), (3, False), (4, True)])

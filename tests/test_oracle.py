@@ -236,6 +236,47 @@ def test_golden_rpn_targets():
     assert (arow == g["argmax_row"]).all() and (acol == g["argmax_col"]).all()
 
 
+def test_golden_roi_delta():
+    g = np.load(os.path.join(GOLDEN, "roi_delta.npz"))
+    hp = synth.hyper_params(total_labels=5, total_pos_bboxes=4, total_neg_bboxes=4)
+    d, l = oracle.roi_delta(g["rois"], g["gt_boxes"], g["gt_labels"], hp, (g["rnd_pos"], g["rnd_neg"]))
+    assert bits_equal(d, g["roi_bbox_deltas"]) and bits_equal(l, g["roi_bbox_labels"])
+    assert l[..., 1:].sum() > 0 and l[..., 0].sum() > 0  # the fixture holds positives and negatives
+
+
+def test_roi_delta_known_answers():
+    """models/faster_rcnn.py:215-234 by hand: one positive (IoU 0.8 with gt 0, label 2), one negative (IoU 0.25), one ignored
+    RoI (disjoint), one zero-padded RoI against a zero-padded gt (IoU NaN -> ignored)."""
+    hp = synth.hyper_params(total_labels=3, total_pos_bboxes=4, total_neg_bboxes=4)
+    gt = np.array([[[0.1, 0.1, 0.6, 0.5], [0.0, 0.0, 0.0, 0.0]]], np.float32)
+    labels = np.array([[2, -1]], np.int32)
+    rois = np.array([[[0.1, 0.1, 0.5, 0.5], [0.1, 0.1, 0.225, 0.5], [0.7, 0.7, 0.9, 0.9], [0, 0, 0, 0]]], np.float32)
+    rnd = np.ones((1, 4), np.int32)
+    d, l = oracle.roi_delta(rois, gt, labels, hp, (rnd, rnd))
+    assert l.tolist() == [[[0, 0, 1], [1, 0, 0], [0, 0, 0], [0, 0, 0]]]
+    d = d.reshape(4, 3, 4)
+    # positive: dy = (0.35 - 0.3) / 0.4 / 0.1, dh = log(0.5 / 0.4) / 0.2, dx = dw = 0, in class slot 2 only
+    np.testing.assert_allclose(d[0, 2], [1.25, 0.0, np.log(1.25) / 0.2, 0.0], rtol=2e-6, atol=1e-6)
+    assert not d[0, :2].any() and not d[1:].any()
+
+
+def test_roi_delta_matches_numpy_restatement():
+    rng = np.random.default_rng(12)
+    B, R, M, L = 3, 200, 9, 7
+    gt, labels = synth.gt_boxes(4, B, M)
+    labels = np.where(labels >= 0, labels % (L - 1) + 1, labels).astype(np.int32)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    rois[:, :2 * M] = np.clip(np.repeat(gt, 2, axis=1) + rng.normal(0, 0.04, (B, 2 * M, 4)), 0, 1)
+    rois[:, -3:] = 0.0
+    rp = rng.integers(1, 100, (B, R), dtype=np.int32)
+    rn = rng.integers(1, 100, (B, R), dtype=np.int32)
+    hp = synth.hyper_params(total_labels=L, total_pos_bboxes=10, total_neg_bboxes=10)
+    d, l = oracle.roi_delta(rois, gt, labels, hp, (rp, rn))
+    nd, nl = npr.roi_delta(rois, gt, labels, L, 10, 10, hp["variances"], rp, rn)
+    assert bits_equal(l, nl) and bits_equal(d, nd)
+    assert l[..., 1:].sum() > 0 and l[..., 0].sum() > 0
+
+
 def test_oracle_threads_agree():
     hp = synth.hyper_params(feature_map_shape=8, pre_nms_topn=200, test_nms_topn=32)
     anchors = oracle.generate_anchors(hp)

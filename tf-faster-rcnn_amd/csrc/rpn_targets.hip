@@ -224,7 +224,102 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   }
 }
 
+// models/faster_rcnn.py:218-234 (RoIDelta.call after the IoU reductions), one image per workgroup.
+// LDS: two R-bit maps, then the per-RoI encoded delta (float4) and label (int).
+__global__ __launch_bounds__(1024) void roi_delta_kernel(
+    const float *__restrict__ rois, const float *__restrict__ gt_boxes, const int *__restrict__ gt_labels,
+    const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int R, int M, int L,
+    int total_pos, int total_neg, float v0, float v1, float v2, float v3, const float *__restrict__ max_iou,
+    const int *__restrict__ argmax_row, float *__restrict__ out_deltas, float *__restrict__ out_labels) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t maps[];
+  __shared__ uint32_t hist[256];
+  __shared__ int misc[8];
+  __shared__ int wsum[kTNW];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int words = (R + 31) >> 5;
+  const int words4 = (2 * words + 3) & ~3;  // keep the float4 array 16-byte aligned
+  uint32_t *pos_sel = maps;
+  uint32_t *neg_sel = maps + words;
+  float4 *s_delta = reinterpret_cast<float4 *>(maps + words4);  // [R]
+  int *s_label = reinterpret_cast<int *>(s_delta + R);           // [R]
+  const float *miou = max_iou + (long long)b * R;
+  const int *rp = rnd_pos ? rnd_pos + (long long)b * R : nullptr;
+  const int *rn = rnd_neg ? rnd_neg + (long long)b * R : nullptr;
+
+  for (int i = tid; i < 2 * words; i += kTNT) maps[i] = 0u;
+  __syncthreads();
+  // :218-219 positives: max IoU > 0.5, sub-sampled to total_pos
+  select_largest(
+      [&](int n) -> int {
+        const int r = rp ? rp[n] : draw_int(seed, 2u, b, n, 10 * total_pos);
+        return ((miou[n] > 0.5f) ? 1 : 0) * r;
+      },
+      R, total_pos, hist, misc, wsum,
+      [&](int n, bool in) {
+        if ((miou[n] > 0.5f) && in) atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
+      });
+  // :220-221 negatives: 0.1 < max IoU < 0.5, sub-sampled to total_neg
+  select_largest(
+      [&](int n) -> int {
+        const int r = rn ? rn[n] : draw_int(seed, 3u, b, n, 10 * total_neg);
+        return (((miou[n] < 0.5f) && (miou[n] > 0.1f)) ? 1 : 0) * r;
+      },
+      R, total_neg, hist, misc, wsum,
+      [&](int n, bool in) {
+        if ((miou[n] < 0.5f) && (miou[n] > 0.1f) && in) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
+      });
+  __syncthreads();
+
+  // :222-230 per RoI: gathered gt box / label, encoded delta / variances
+  for (int n = tid; n < R; n += kTNT) {
+    const bool pos = (pos_sel[n >> 5] >> (n & 31)) & 1u;
+    const bool neg = (neg_sel[n >> 5] >> (n & 31)) & 1u;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    int lab = -1;
+    if (pos) {
+      const int m = argmax_row[(long long)b * R + n];
+      g = *reinterpret_cast<const float4 *>(gt_boxes + ((long long)b * M + m) * 4);
+      lab = gt_labels[(long long)b * M + m];
+    }
+    lab += neg ? 1 : 0;
+    const float4 a = *reinterpret_cast<const float4 *>(rois + ((long long)b * R + n) * 4);
+    float4 d = encode_box(a, g);
+    d.x = d.x / v0;
+    d.y = d.y / v1;
+    d.z = d.z / v2;
+    d.w = d.w / v3;
+    s_delta[n] = d;
+    s_label[n] = lab;
+  }
+  __syncthreads();
+
+  // :231-234 one-hot labels (B,R,L) and the "scatter" = one-hot * delta (a multiply: 0 * delta keeps sign / NaN), (B,R*L,4)
+  const long long total = (long long)R * L;
+  float *ol = out_labels + (long long)b * total;
+  float4 *od = reinterpret_cast<float4 *>(out_deltas) + (long long)b * total;
+  int n = tid / L, l = tid - n * L;
+  const int dn = kTNT / L, dl = kTNT - dn * L;
+  for (long long e = tid; e < total; e += kTNT) {
+    const float oh = (s_label[n] == l) ? 1.0f : 0.0f;
+    const float4 d = s_delta[n];
+    float4 o;
+    o.x = oh * d.x;
+    o.y = oh * d.y;
+    o.z = oh * d.z;
+    o.w = oh * d.w;
+    ol[e] = oh;
+    od[e] = o;
+    n += dn;
+    l += dl;
+    if (l >= L) {
+      l -= L;
+      ++n;
+    }
+  }
+}
+
 static const int kMaxTargetsN = 262144;
+static const int kMaxRoiDeltaR = 4096;
 
 }  // namespace frcnn
 
@@ -292,6 +387,48 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
                      rnd_neg, (unsigned long long)seed, N, M, total_pos, total_neg, variances[0], variances[1],
                      variances[2], variances[3], max_iou, argmax_row, argmax_col, out_deltas, out_labels);
   return check_launch("rpn_targets");
+}
+
+size_t frcnn_roi_delta_workspace_bytes(int B, int R, int M) {
+  (void)M;
+  if (B < 0 || R < 0) return 0;
+  return 2 * round_up((size_t)B * (R > 0 ? R : 1) * 4, 256) + 256;  // max_iou, argmax_row
+}
+
+int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_labels, const int32_t *rnd_pos,
+                    const int32_t *rnd_neg, uint64_t seed, int B, int R, int M, int total_labels, int total_pos,
+                    int total_neg, const float *variances, float *out_deltas, float *out_labels, void *workspace,
+                    size_t workspace_bytes, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(rois && gt_boxes && gt_labels && variances && out_deltas && out_labels, "roi_delta: null pointer");
+  FRCNN_REQUIRE((rnd_pos == nullptr) == (rnd_neg == nullptr), "roi_delta: give both random tensors or neither");
+  FRCNN_REQUIRE(B >= 0 && R >= 0 && M > 0 && total_labels > 0, "roi_delta: bad shape B=%d R=%d M=%d L=%d", B, R, M, total_labels);
+  FRCNN_REQUIRE(total_labels <= 1024, "roi_delta: total_labels=%d exceeds 1024", total_labels);
+  FRCNN_REQUIRE(total_pos >= 0 && total_neg >= 0, "roi_delta: negative sample counts");
+  FRCNN_REQUIRE(aligned_to(rois, 16) && aligned_to(gt_boxes, 16) && aligned_to(out_deltas, 16),
+                "roi_delta: box pointers must be 16-byte aligned");
+  if (R > kMaxRoiDeltaR)
+    return set_error(FRCNN_EUNSUPPORTED, "roi_delta: R=%d RoIs per image exceeds the LDS limit %d", R, kMaxRoiDeltaR);
+  FRCNN_REQUIRE(workspace && aligned_to(workspace, 256) && workspace_bytes >= frcnn_roi_delta_workspace_bytes(B, R, M),
+                "roi_delta: workspace must be non-null, 256-byte aligned and >= %zu bytes", frcnn_roi_delta_workspace_bytes(B, R, M));
+  if (B == 0 || R == 0) return FRCNN_OK;
+  unsigned char *p = reinterpret_cast<unsigned char *>(workspace);
+  float *max_iou = reinterpret_cast<float *>(p);
+  int *argmax_row = reinterpret_cast<int *>(p + round_up((size_t)B * R * 4, 256));
+  // :215-217 RoI x gt IoU, row max and first argmax (RoIs are per image: batched boxes); no map is written
+  int rc = frcnn_iou_map_reduce(rois, 1, gt_boxes, B, R, M, max_iou, argmax_row, nullptr, nullptr, 0, stream);
+  if (rc) return rc;
+  const int words = (R + 31) >> 5;
+  const size_t lds = (size_t)((2 * words + 3) & ~3) * 4 + (size_t)R * 20;
+  auto kern = roi_delta_kernel;
+  if (lds > 48 * 1024) {
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                   "roi_delta: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTNT), lds, (hipStream_t)stream, rois, gt_boxes, gt_labels, rnd_pos, rnd_neg,
+                     (unsigned long long)seed, R, M, total_labels, total_pos, total_neg, variances[0], variances[1],
+                     variances[2], variances[3], max_iou, argmax_row, out_deltas, out_labels);
+  return check_launch("roi_delta");
 }
 
 }  // extern "C"

@@ -1,4 +1,4 @@
-"""Proposal / RoI layers -- drop-in for ``RoIBBox``, ``RoIPooling`` and ``Decoder`` of the
+"""Proposal / RoI layers -- drop-in for ``RoIBBox``, ``RoIDelta``, ``RoIPooling`` and ``Decoder`` of the
 reference's ``models/faster_rcnn.py``.
 
 Same constructors, ``call(inputs)`` contracts and ``get_config()`` keys as the Keras layers they
@@ -8,7 +8,7 @@ the RPN head and the dense heads are out of scope: their outputs enter as tensor
 
 from __future__ import annotations
 
-from typing import Any, Dict, Sequence, Tuple
+from typing import Any, Dict, Optional, Sequence, Tuple
 
 import torch
 
@@ -45,8 +45,8 @@ class Layer:
     def call(self, inputs: Sequence[torch.Tensor]) -> Any:  # pragma: no cover - abstract
         raise NotImplementedError
 
-    def __call__(self, inputs: Sequence[torch.Tensor]) -> Any:
-        return self.call(inputs)
+    def __call__(self, inputs: Sequence[torch.Tensor], **kwargs: Any) -> Any:
+        return self.call(inputs, **kwargs)
 
 
 class Decoder(Layer):
@@ -156,6 +156,75 @@ class RoIBBox(Layer):
                                       nms_iou_threshold, _lib.ptr(out), None, None, _lib.ptr(ws), ws.numel(),
                                       _lib.stream_ptr(device)))
         return out
+
+
+class RoIDelta(Layer):
+    """Build Faster R-CNN regression and classification targets for sampled RoIs.
+
+    Mirrors reference ``models/faster_rcnn.py:169-235``.
+    """
+
+    def __init__(self, hyper_params: HyperParams, **kwargs: Any) -> None:
+        super().__init__(**kwargs)
+        self.hyper_params = hyper_params
+
+    def get_config(self) -> Dict[str, Any]:
+        config = super().get_config()
+        config.update({"hyper_params": self.hyper_params})
+        return config
+
+    def call(self, inputs: Sequence[torch.Tensor], random_masks: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+             seed: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``inputs = [roi_bboxes (B,R,4), gt_boxes (B,M,4), gt_labels (B,M) int32]``.
+
+        RoI x gt IoU (``:215``), per-RoI best gt and max IoU (``:216-217``), positives ``> 0.5`` sampled to
+        ``total_pos_bboxes`` (``:218-219``), negatives in ``(0.1, 0.5)`` sampled to ``total_neg_bboxes`` (``:220-221``),
+        gathered gt boxes / labels (``:222-229``; positives keep their gt label, negatives get label 0, the rest -1),
+        ``get_deltas_from_bboxes / variances`` (``:230``), ``one_hot`` labels and the per-class delta scatter
+        (``:231-234``).
+
+        Extra arguments (the reference draws from TF's unseeded RNG): ``random_masks = (pos, neg)``, two int32
+        ``(B,R)`` tensors holding the random integers of the two sampling calls; ``seed`` for the in-kernel draw
+        otherwise.
+
+        Returns:
+            ``(roi_bbox_deltas (B, R*total_labels, 4), roi_bbox_labels (B, R, total_labels))``, fp32, no gradient
+            (``:235``).
+        """
+        rois = _lib.device_tensor(inputs[0], torch.float32)
+        device = rois.device
+        gt = _lib.device_tensor(inputs[1], torch.float32, device)
+        lab = _lib.device_tensor(inputs[2], torch.int32, device)
+        hp = self.hyper_params
+        L = int(hp["total_labels"])
+        total_pos, total_neg = int(hp["total_pos_bboxes"]), int(hp["total_neg_bboxes"])
+        if rois.dim() != 3 or rois.shape[2] != 4:
+            raise ValueError(f"roi_bboxes must be (batch, total_bboxes, 4), got {tuple(rois.shape)}")
+        B, R, _ = rois.shape
+        if gt.dim() != 3 or gt.shape[0] != B or gt.shape[2] != 4:
+            raise ValueError(f"gt_boxes must be ({B}, padded_gt_boxes, 4), got {tuple(gt.shape)}")
+        M = gt.shape[1]
+        if M < 1:
+            raise ValueError("gt_boxes needs at least one (possibly padded) box per image")  # TF: gather from an empty axis
+        if tuple(lab.shape) != (B, M):
+            raise ValueError(f"gt_labels must be ({B}, {M}), got {tuple(lab.shape)}")
+        rp = rn = None
+        if random_masks is not None:
+            rp = _lib.device_tensor(random_masks[0], torch.int32, device)
+            rn = _lib.device_tensor(random_masks[1], torch.int32, device)
+            if tuple(rp.shape) != (B, R) or tuple(rn.shape) != (B, R):
+                raise ValueError("random_masks must be two (batch, total_bboxes) tensors")
+        if seed is None:
+            seed = 0 if random_masks is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
+        deltas = torch.empty((B, R * L, 4), dtype=torch.float32, device=device)
+        labels = torch.empty((B, R, L), dtype=torch.float32, device=device)
+        lib = _lib.lib()
+        ws = _lib.workspace(lib.frcnn_roi_delta_workspace_bytes(B, R, M), device)
+        _lib.check(lib.frcnn_roi_delta(_lib.ptr(rois), _lib.ptr(gt), _lib.ptr(lab), _lib.ptr(rp), _lib.ptr(rn),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, B, R, M, L, total_pos, total_neg,
+                                       _lib.float4(hp["variances"]), _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws),
+                                       ws.numel(), _lib.stream_ptr(device)))
+        return deltas, labels
 
 
 class RoIPooling(Layer):
