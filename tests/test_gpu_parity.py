@@ -504,6 +504,67 @@ def test_roi_delta_errors(pkg):
 
 
 # ------------------------------------------------------------------------------------------------
+# other callers of the same kernels
+# ------------------------------------------------------------------------------------------------
+def test_rpn_predictor_call_pattern(pkg):
+    """rpn_predictor.py:58-65: reshape, * variances, decode, top_k(scores, 10), gather."""
+    B, G = 4, 32
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    anchors = oracle.generate_anchors(hp)
+    deltas, scores = synth.rpn_outputs(3, B, G)
+    var = torch.tensor(hp["variances"], dtype=torch.float32).cuda()
+    d = dev(deltas).reshape(B, -1, 4) * var
+    boxes = pkg.bbox_utils.get_bboxes_from_deltas(dev(anchors), d)
+    _, top = pkg.bbox_utils.top_k(dev(scores).reshape(B, -1), 10)
+    got = torch.gather(boxes, 1, top.long()[..., None].expand(-1, -1, 4))
+    wd = (deltas.reshape(B, -1, 4) * np.asarray(hp["variances"], np.float32)).astype(np.float32)
+    wboxes = oracle.get_bboxes_from_deltas(anchors, wd)
+    _, wtop = oracle.top_k(scores.reshape(B, -1), 10)
+    assert_bits(top, wtop, "top-10 indices")
+    assert_bits(got, np.take_along_axis(wboxes, wtop[..., None].astype(np.int64), axis=1), "top-10 boxes")
+
+
+def test_eval_match_predictions_and_update_stats(pkg):
+    """utils/eval_utils.py:69-72 (device) and :73-97 (host loop) against the oracle's map + NumPy reductions."""
+    B, R, M, L = 3, 200, 7, 6
+    rois, gt, labels = _roi_delta_case(9, B, R, M, L)
+    merged, arg, order = pkg.eval_utils.match_predictions(dev(rois), dev(gt))
+    iou = oracle.generate_iou_map(rois, gt)
+    filled = np.where(np.isnan(iou), -np.inf, iou)
+    wm = filled.max(-1)
+    wm = np.where(np.isinf(wm), np.float32(-3.402823466e38), wm).astype(np.float32)
+    assert_bits(merged, wm, "merged_iou_map")
+    assert_bits(arg, filled.argmax(-1).astype(np.int32), "max_indices_each_gt")
+    _, worder = oracle.top_k(wm, R)
+    assert_bits(order, worder, "sorted_ids")
+    rng = np.random.default_rng(2)
+    pl = rng.integers(0, L, (B, R)).astype(np.int32)
+    ps = rng.random((B, R)).astype(np.float32)
+    stats = pkg.eval_utils.update_stats(dev(rois), dev(pl), dev(ps), dev(gt), dev(labels),
+                                        pkg.eval_utils.init_stats([f"c{i}" for i in range(L)]))
+    # restated by hand from the reference's loop
+    want = {i: {"total": 0, "tp": [], "fp": []} for i in range(1, L)}
+    for v in labels.reshape(-1):
+        if v != -1:
+            want[int(v)]["total"] += 1
+    for b in range(B):
+        seen = []
+        for r in worder[b]:
+            c = int(pl[b, r])
+            if c == 0:
+                continue
+            g = int(filled[b, r].argmax())
+            ok = wm[b, r] >= 0.5 and c == int(labels[b, g]) and g not in seen
+            want[c]["tp"].append(int(ok))
+            want[c]["fp"].append(int(not ok))
+            if ok:
+                seen.append(g)
+    for c in want:
+        assert stats[c]["total"] == want[c]["total"] and stats[c]["tp"] == want[c]["tp"] and stats[c]["fp"] == want[c]["fp"]
+    assert sum(sum(s["tp"]) for s in stats.values()) > 0
+
+
+# ------------------------------------------------------------------------------------------------
 # stage pipeline over streams
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("depth,heads_callable", [(1, False), (3, False), (4, True)])

@@ -8,7 +8,7 @@ reference's ``models/faster_rcnn.py``, ``utils/bbox_utils.py`` and ``utils/train
 
 from . import _lib, sharding  # noqa: F401
 from .models import faster_rcnn  # noqa: F401
-from .utils import bbox_utils, train_utils  # noqa: F401
+from .utils import bbox_utils, eval_utils, train_utils  # noqa: F401
 from . import pipeline  # noqa: F401,E402
 
 __version__ = "0.1.0"
