@@ -564,6 +564,29 @@ def test_eval_match_predictions_and_update_stats(pkg):
     assert sum(sum(s["tp"]) for s in stats.values()) > 0
 
 
+def test_generators_prefetch_targets_on_side_stream(pkg):
+    """utils/train_utils.py:91-136: endless feeders; targets of the next batch are computed on a side stream."""
+    import itertools
+
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=16)
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    data = []
+    for i in range(3):
+        gt, lab = synth.gt_boxes(i, 2, 6)
+        data.append((torch.full((2, 4), float(i)), dev(gt), dev(lab)))
+    gen = pkg.train_utils.faster_rcnn_generator(data, anchors, hp, prefetch=2, seed=100)
+    items = list(itertools.islice(gen, 7))  # more than two passes over the 3-batch dataset
+    for i, ((img, gt, lab, deltas, labels), empty) in enumerate(items):
+        assert empty == () and float(img[0, 0]) == float(i % 3)
+        wd, wl = pkg.train_utils.calculate_rpn_actual_outputs(anchors, data[i % 3][1], data[i % 3][2], hp, seed=100 + i)
+        assert_bits(deltas, wd.cpu().numpy(), f"generator batch {i} deltas")
+        assert_bits(labels, wl.cpu().numpy(), f"generator batch {i} labels")
+    img, (deltas, labels) = next(pkg.train_utils.rpn_generator(data, anchors, hp, prefetch=0, seed=100))
+    assert_bits(deltas, items[0][0][3].cpu().numpy(), "rpn_generator deltas")
+    with pytest.raises(ValueError):
+        next(pkg.train_utils.rpn_generator([], anchors, hp))
+
+
 # ------------------------------------------------------------------------------------------------
 # stage pipeline over streams
 # ------------------------------------------------------------------------------------------------

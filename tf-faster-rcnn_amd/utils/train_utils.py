@@ -1,13 +1,15 @@
 """Training-time helpers on the proposal path -- drop-in for the reference's ``utils/train_utils.py``.
 
-Covers the hyper-parameter table, ``randomly_select_xyz_mask`` and ``calculate_rpn_actual_outputs``.
-Losses, generators and the data pipeline are out of scope.
+Covers the hyper-parameter table, ``randomly_select_xyz_mask``, ``calculate_rpn_actual_outputs`` and the two batch
+feeders built on it (``faster_rcnn_generator``, ``rpn_generator``), which compute the targets of the next batch on a
+side stream.  Losses and the data pipeline are out of scope.
 """
 
 from __future__ import annotations
 
 import math
-from typing import Any, Dict, Optional, Sequence, Tuple
+from collections import deque
+from typing import Any, Dict, Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
 
@@ -157,3 +159,64 @@ def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, 
                                    int(seed) & 0xFFFFFFFFFFFFFFFF, B, N, M, total_pos, total_neg, variances,
                                    _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
     return deltas, labels.reshape(B, feature_map_shape, feature_map_shape, anchor_count)
+
+
+
+def _rpn_target_batches(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.Tensor, hyper_params: HyperParams,
+                        prefetch: int, seed: Optional[int]) -> Iterator[Tuple[torch.Tensor, ...]]:
+    """Endless ``(img, gt_boxes, gt_labels, bbox_deltas, bbox_labels)`` stream over ``dataset`` (re-iterated forever, as
+    the reference's ``while True``).  Target assignment for up to ``prefetch`` batches ahead is enqueued on a side HIP
+    stream, off the consumer's stream (the reference computes it eagerly on the Python feeder thread,
+    ``utils/train_utils.py:108-112``); the consumer's current stream waits on the batch's event when it is handed over."""
+    anchors_t = _lib.device_tensor(anchors, torch.float32)
+    device = anchors_t.device
+    side = torch.cuda.Stream(device)
+    pending: deque = deque()
+    counter = 0
+    while True:
+        produced = False
+        for img, gt_boxes, gt_labels in dataset:
+            produced = True
+            gt_t = _lib.device_tensor(gt_boxes, torch.float32, device)
+            lab_t = _lib.device_tensor(gt_labels, torch.int32, device)
+            ready = _lib.HipEvent()
+            ready.record(torch.cuda.current_stream(device).cuda_stream)  # the gt tensors come from the caller's stream
+            ready.wait(side.cuda_stream)
+            with torch.cuda.stream(side):
+                deltas, labels = calculate_rpn_actual_outputs(anchors_t, gt_t, lab_t, hyper_params,
+                                                              seed=None if seed is None else seed + counter)
+            done = _lib.HipEvent()
+            done.record(side.cuda_stream)
+            counter += 1
+            pending.append((img, gt_t, lab_t, deltas, labels, done))
+            if len(pending) > prefetch:
+                yield _hand_over(pending.popleft(), device)
+        if not produced:
+            raise ValueError("the dataset yielded no batch")
+        # the reference's generators never end; keep `prefetch` batches in flight across passes
+
+
+def _hand_over(item: Tuple[Any, ...], device: torch.device) -> Tuple[torch.Tensor, ...]:
+    img, gt_t, lab_t, deltas, labels, done = item
+    cur = torch.cuda.current_stream(device)
+    done.wait(cur.cuda_stream)
+    deltas.record_stream(cur)  # allocated on the side stream, consumed on the caller's
+    labels.record_stream(cur)
+    return img, gt_t, lab_t, deltas, labels
+
+
+def faster_rcnn_generator(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.Tensor, hyper_params: HyperParams,
+                          prefetch: int = 1, seed: Optional[int] = None) -> Iterator[Tuple[Tuple[torch.Tensor, ...], Tuple[()]]]:
+    """Yield ``((img, gt_boxes, gt_labels, bbox_deltas, bbox_labels), ())`` forever.  Mirrors reference
+    ``utils/train_utils.py:91-112``; ``dataset`` is any re-iterable of padded ``(img, gt_boxes, gt_labels)`` batches.
+    Extra arguments: ``prefetch`` batches of targets kept in flight on a side stream; ``seed`` makes the sampling
+    reproducible (batch ``i`` uses ``seed + i``)."""
+    for batch in _rpn_target_batches(dataset, anchors, hyper_params, max(0, int(prefetch)), seed):
+        yield batch, ()
+
+
+def rpn_generator(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.Tensor, hyper_params: HyperParams,
+                  prefetch: int = 1, seed: Optional[int] = None) -> Iterator[Tuple[Any, Tuple[torch.Tensor, torch.Tensor]]]:
+    """Yield ``(img, (bbox_deltas, bbox_labels))`` forever.  Mirrors reference ``utils/train_utils.py:115-136``."""
+    for img, _, _, deltas, labels in _rpn_target_batches(dataset, anchors, hyper_params, max(0, int(prefetch)), seed):
+        yield img, (deltas, labels)
