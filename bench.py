@@ -117,6 +117,8 @@ def main() -> None:
                     help="pipeline: stages on three HIP streams, --depth batches in flight (tf_faster_rcnn_amd.pipeline); "
                          "sequential: the three layers one after the other on one stream")
     ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--no-other-schedule", action="store_true",
+                    help="do not time the other schedule afterwards (profiling runs: one schedule per kernel trace)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -200,7 +202,7 @@ def main() -> None:
     crop_ms = float(np.mean([a.elapsed_time(b) for i, (a, b) in enumerate(zip(ev0, ev1))
                              if args.mode == "sequential" or i % TIME_EVERY == 0])) if args.steps else float("nan")
     other = None
-    if world == 1:  # the other schedule, same K steps, reported beside the headline (not part of `value`)
+    if world == 1 and not args.no_other_schedule:  # the other schedule, same K steps, reported beside the headline (not part of `value`)
         other_elapsed = timed(step_sequential if args.mode == "pipeline" else step_pipeline, False)
         other = {"mode": "sequential" if args.mode == "pipeline" else "pipeline",
                  "value": round(cfg["B"] * args.steps / other_elapsed, 1),
