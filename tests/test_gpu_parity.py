@@ -334,6 +334,17 @@ def test_roi_pooling(pkg, B, G, C, R):
     assert_bits(got, want, "RoIPooling")
 
 
+def test_roi_pooling_channel_slice_kernel(pkg, monkeypatch):
+    """The kernel used for feature maps larger than an XCD's L2 (each XCD owns an eighth of the channels): forced on small
+    shapes (incl. a depth that leaves the last slices empty), and taken by itself on a 63x63x576 map."""
+    monkeypatch.setenv("FRCNN_CROP_SLICE", "1")
+    test_roi_pooling(pkg, 2, 8, 8, 16)
+    test_roi_pooling(pkg, 2, 31, 512, 64)
+    test_roi_pooling(pkg, 1, 9, 20, 33)
+    monkeypatch.delenv("FRCNN_CROP_SLICE")
+    test_roi_pooling(pkg, 1, 63, 576, 40)
+
+
 def test_crop_and_resize_generic(pkg):
     rng = np.random.default_rng(13)
     img = rng.normal(size=(3, 6, 9, 5)).astype(np.float32)

@@ -139,6 +139,62 @@ __device__ __forceinline__ vec_t bilerp(const char *__restrict__ base, const Pix
   return v;
 }
 
+// Channel-slice kernel for feature maps that do not fit an XCD's L2 (e.g. 63x63x576 = 9.1 MB per image): the 8 XCDs
+// each own one eighth of the channels (blockIdx % 8 = slice) and all of them walk the boxes in order, so an XCD's L2 only
+// has to hold 1/8 of the current image.  One workgroup = (box, slice): ch*cw segments of SW float4, strided by C floats.
+__global__ __launch_bounds__(256) void crop_resize_slice_kernel(
+    const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
+    const int *__restrict__ box_ind, int n, int boxes_per_image, int ch, int cw, float extrap,
+    float *__restrict__ out, int SW) {
+  __shared__ PixParam pp[256];
+  const int tid = threadIdx.x;
+  const int slice = blockIdx.x & 7;
+  const int box = blockIdx.x >> 3;
+  const int CV = C >> 2;
+  const int c0 = slice * SW;
+  const int sw = (CV - c0 < SW) ? (CV - c0) : SW;  // float4 channels of this slice (may be <= 0 for the last ones)
+  if (sw <= 0) return;
+  const int bimg = box_ind ? box_ind[box] : (box / boxes_per_image);
+  const bool img_ok = (bimg >= 0) && (bimg < B);
+  const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + (long long)box * 4);
+  const int P = ch * cw;
+  const char *__restrict__ base =
+      reinterpret_cast<const char *>(image + (long long)(img_ok ? bimg : 0) * H * W * C) + (size_t)c0 * 16;
+  char *__restrict__ dstb = reinterpret_cast<char *>(out + (long long)box * P * C) + (size_t)c0 * 16;
+  const unsigned pix_bytes = (unsigned)C * 4u;
+
+  for (int p0 = 0; p0 < P; p0 += 256) {
+    const int np = (P - p0 < 256) ? (P - p0) : 256;
+    if (p0 > 0) __syncthreads();
+    if (tid < np) pp[tid] = pix_param(p0 + tid, H, W, pix_bytes, ch, cw, bx.x, bx.y, bx.z, bx.w, img_ok);
+    __syncthreads();
+    const int total = np * sw;
+    int p = tid / sw;
+    int c = tid - p * sw;
+    const int dp = 256 / sw, dc = 256 - dp * sw;
+    for (int e0 = tid; e0 < total; e0 += 256 * 4) {
+      f32x4 v[4];
+      unsigned off[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = e0 + u * 256 < total;
+        const int pu = in ? p : 0, cu = in ? c : 0;
+        v[u] = bilerp<f32x4>(base, pp[pu], (unsigned)cu * 16u, extrap);
+        off[u] = (unsigned)(p0 + pu) * pix_bytes + (unsigned)cu * 16u;
+        c += dc;
+        p += dp;
+        if (c >= sw) {
+          c -= sw;
+          ++p;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + u * 256 < total) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4 *>(dstb + (size_t)off[u]));
+    }
+  }
+}
+
 #ifndef FRCNN_CROP_WAVES_PER_EU
 #define FRCNN_CROP_WAVES_PER_EU 4
 #endif
@@ -240,6 +296,21 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   if (n == 0) return FRCNN_OK;
   const bool vec4 = (C % 4 == 0) && aligned_to(image, 16) && aligned_to(out, 16);
   dim3 grid((unsigned)n), block(256);
+  // The box kernel keeps the one or two images an XCD is working on in its 4 MiB L2.  An image that does not fit there
+  // (e.g. 63x63x576 = 9.1 MB) is read through the channel-slice kernel instead, each XCD holding one eighth of it
+  // (measured: 179 against 232 us at config 5; 23 % slower than the box kernel at config 2, whose images fit).
+  // FRCNN_CROP_SLICE=0|1 forces the choice (diagnostic).
+  const char *force_env = getenv("FRCNN_CROP_SLICE");
+  const int force_slice = force_env ? atoi(force_env) : -1;
+  bool use_slice = false;
+  if (vec4 && aligned_to(boxes, 16) && (long long)n * 8 < (1ll << 31) && (long long)crop_h * crop_w * C * 4 < (1ll << 32))
+    use_slice = force_slice >= 0 ? force_slice != 0 : (double)H * W * C * 4 > 4.0 * 1024 * 1024;
+  if (use_slice) {
+    const int CV = C / 4, SW = (CV + 7) / 8;
+    hipLaunchKernelGGL(crop_resize_slice_kernel, dim3((unsigned)n * 8u), block, 0, (hipStream_t)stream, image, B, H, W, C,
+                       boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out, SW);
+    return check_launch("crop_and_resize");
+  }
   if (vec4) {
     hipLaunchKernelGGL(crop_resize_kernel<4>, grid, block, 0, (hipStream_t)stream, image, B, H, W,
                        C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value,
