@@ -300,6 +300,19 @@ def test_roi_bbox_unfused_path(pkg, monkeypatch):
     assert_bits(got, want, "RoIBBox unfused cfg5")
 
 
+def test_roi_bbox_bitmask_path(pkg, monkeypatch):
+    """The whole-chip bitmask schedule (taken for post_nms_topn >= 1024), forced on every shape: one and several phases,
+    early finish, exhausted candidates, ties, K not a multiple of 64, R larger than K."""
+    monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "1")
+    for args, kw in (((10, 2, 8, 64, 16), {}), ((11, 2, 16, 2304, 300), {}), ((12, 4, 32, 6000, 300), {}),
+                     ((13, 3, 31, 6000, 2000), dict(mode="training")), ((14, 2, 16, 1000, 100), dict(unique=False, thr=0.5)),
+                     ((15, 2, 63, 12000, 1500), dict(mode="training")), ((16, 2, 8, 570, 600), {}),
+                     ((17, 2, 16, 2304, 1500), dict(thr=0.1))):
+        got, want = _roi_bbox_case(pkg, *args, **kw)
+        assert_bits(got, want, f"RoIBBox bitmask {args} {kw}")
+    test_roi_bbox_dense_suppression(pkg)
+
+
 def test_roi_bbox_dense_suppression(pkg):
     """Heavily overlapping proposals (tiny deltas, IoU threshold 0.1): several slices and chunks are consumed."""
     hp = pkg.train_utils.get_hyper_params("mobilenet_v2")

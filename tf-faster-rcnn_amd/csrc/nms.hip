@@ -354,6 +354,13 @@ int launch_proposal(const float *deltas, const float *scores, const float *ancho
                     int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
                     int *out_valid, hipStream_t stream, bool *handled);
 
+// nms_bitmask.hip
+bool roi_bbox_bitmask_applies(int B, int K, int R_nms);
+size_t roi_bbox_bitmask_workspace_bytes(int B, int K, int R_nms);
+int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
+                            int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
+                            int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream);
+
 // decoder.hip
 int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
                    int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
@@ -407,7 +414,12 @@ int frcnn_combined_nms(const float *boxes, const float *scores, int B, int n, in
 size_t frcnn_roi_bbox_workspace_bytes(int B, int N, int K, int R) {
   if (B < 0 || N < 0 || K < 0) return 0;
   const int Rr = R < K ? R : K;
-  return carve_workspace(nullptr, B, K, Rr > 0 ? Rr : 1).bytes;
+  size_t bytes = carve_workspace(nullptr, B, K, Rr > 0 ? Rr : 1).bytes;
+  if (roi_bbox_bitmask_applies(B, K, Rr)) {
+    const size_t bm = roi_bbox_bitmask_workspace_bytes(B, K, Rr);
+    if (bm > bytes) bytes = bm;
+  }
+  return bytes;
 }
 
 int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchors,
@@ -427,6 +439,10 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
     if (!(force && force[0] == '1')) {
       bool handled = false;
       const int Rn = R < K ? R : K;
+      // large post_nms_topn (training): the pair tests go to the whole chip (nms_bitmask.hip)
+      if (roi_bbox_bitmask_applies(B, K, Rn))
+        return launch_roi_bbox_bitmask(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
+                                       out_scores, out_valid, workspace, workspace_bytes, (hipStream_t)stream);
       int rc = launch_proposal(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
                                out_scores, out_valid, (hipStream_t)stream, &handled);
       if (rc || handled) return rc;

@@ -1,0 +1,396 @@
+// nms_bitmask.hip -- RoIBBox for LARGE post_nms_topn (training: train_nms_topn = 1500..2000): the pair tests of the
+// greedy NMS spread over the whole chip.
+//
+// Replaces models/faster_rcnn.py:153-164 like proposal.hip; same results, different schedule.  The fused
+// one-workgroup-per-image kernel (proposal.hip) tests every 128-candidate chunk against the kept list on ONE CU: at
+// R = 2000 that is ~3 M pair tests per image, 1.6 ms per 16 images.  Here:
+//   1. sort_select orders the top-K candidates (score desc, index asc) -- sort_select.hip;
+//   2. `bm_prepare_kernel` decodes them once into packed boxes (corner-normalised box, area, flags);
+//   3. per PHASE (a band of kBandBlocks 64-candidate column blocks, i.e. 2048 candidates):
+//      `bm_tiles_kernel` (whole grid): for every 64x64 tile (row block rb <= column block cb of the band) the
+//         suppression words mask[cb][row] = ballot over the 64 column boxes of "IoU(row, col) > thr and row before col".
+//         Row blocks of EARLIER bands in which nothing was kept are skipped (their rows can suppress nobody);
+//      `bm_scan_kernel` (one workgroup per image): folds the kept rows of earlier bands into the band's `removed`
+//         words, then walks the band's blocks in order: wave 0 resolves the greedy order inside a block on scalar
+//         registers (as nms_core.hpp), the other waves OR the kept rows' words into the later blocks of the band.
+//      An image that has its R boxes (or runs out of candidates) writes its outputs and marks itself done; later phases
+//      return at once for it, so the work is proportional to the candidates actually consumed, in bands of 2048.
+// All state between kernels lives in the caller's workspace; nothing synchronises with the host.
+#include <stdlib.h>
+
+#include "nms_core.hpp"
+#include "sort_select.hpp"
+
+namespace frcnn {
+
+static const int kBandBlocks = 32;  // column blocks (of 64 candidates) per phase
+
+struct BitmaskParams {
+  const float *deltas;   // (B,N,4)
+  const float *scores;   // (B,N)
+  const float *anchors;  // (N,4)
+  float v0, v1, v2, v3;
+  int N, K, R_nms, R_out;
+  IouThr iou;
+  float score_thr;
+  int nb;                // 64-candidate blocks = ceil(K / 64)
+  // workspace (per image strides in elements)
+  const int *sorted_idx;        // (B,K)
+  float4 *pbox;                 // (B, nb*64)
+  float2 *paf;                  // (B, nb*64)   (area, flags as int bits)
+  unsigned long long *mask;     // (B, nb, nb*64)   mask[cb][row]
+  unsigned long long *diag_t;   // (B, nb*64)  transposed diagonal tiles: bit r of diag_t[col] = "row r of col's block suppresses col"
+  unsigned long long *removed;  // (B, nb)
+  unsigned long long *keptmap;  // (B, nb)
+  int *state;                   // (B, 4): nk, done
+  int *kidx;                    // (B, R_nms) sorted positions of the kept boxes
+  float *out_boxes;             // (B,R_out,4)
+  float *out_scores;            // (B,R_out) or NULL
+  int *out_valid;               // (B) or NULL
+};
+
+// grid (nb/4 rounded up, B), block 256: wave w <-> block 4*blockIdx.x + w.
+__global__ __launch_bounds__(256) void bm_prepare_kernel(BitmaskParams p) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int blk = blockIdx.x * 4 + w;
+  if (blk >= p.nb) return;
+  const int Kp = p.nb * 64;
+  const int j = blk * 64 + lane;
+  NBox nb;
+  nb.ymin = nb.xmin = nb.ymax = nb.xmax = nb.area = 0.0f;
+  int fl = 0;
+  bool bad = true;  // positions beyond K never exist
+  if (j < p.K) {
+    const int ei = p.sorted_idx[(long long)b * p.K + j];
+    const float4 a = reinterpret_cast<const float4 *>(p.anchors)[ei];
+    const float4 d = reinterpret_cast<const float4 *>(p.deltas)[(long long)b * p.N + ei];
+    const float4 box = decode_box(a, scale_deltas(d, p.v0, p.v1, p.v2, p.v3));
+    nb = normalise_box(box);
+    fl = box_flags(box, nb);
+    bad = !(p.scores[(long long)b * p.N + ei] > p.score_thr);
+  }
+  p.pbox[(long long)b * Kp + j] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
+  p.paf[(long long)b * Kp + j] = make_float2(nb.area, __int_as_float(fl));
+  const unsigned long long badw = __ballot(bad);
+  if (lane == 0) {
+    p.removed[(long long)b * p.nb + blk] = badw;
+    p.keptmap[(long long)b * p.nb + blk] = 0ull;
+    if (blk == 0) {
+      p.state[b * 4 + 0] = 0;
+      p.state[b * 4 + 1] = 0;
+    }
+  }
+}
+
+// grid (band column blocks, ceil(row blocks / 4), B), block 256: wave w <-> row block 4*blockIdx.y + w.
+__global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0) {
+  __shared__ float4 s_box[4][64];
+  __shared__ float2 s_af[4][64];
+  const int b = blockIdx.z;
+  if (p.state[b * 4 + 1]) return;  // image finished in an earlier phase
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cb = cb0 + blockIdx.x;
+  const int rb = blockIdx.y * 4 + w;
+  if (cb >= p.nb || rb > cb) return;  // wave-uniform
+  // rows of an earlier band that kept nothing cannot suppress: the scan never reads their words
+  if (rb < cb0 && p.keptmap[(long long)b * p.nb + rb] == 0ull) return;
+  const int Kp = p.nb * 64;
+  const float4 *pbox = p.pbox + (long long)b * Kp;
+  const float2 *paf = p.paf + (long long)b * Kp;
+  s_box[w][lane] = pbox[rb * 64 + lane];
+  s_af[w][lane] = paf[rb * 64 + lane];
+  const int jcol = cb * 64 + lane;
+  const PBox me = load_pbox(pbox, paf, jcol);
+  // wave-private LDS rows: LDS operations of a wave complete in order; keep the compiler from hoisting the reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  unsigned long long mine = 0ull, mycol = 0ull;
+  for (int r0 = 0; r0 < 64; r0 += 4) {
+    PBox rbx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rbx[u] = load_pbox(s_box[w], s_af[w], r0 + u);
+    bool irr = false;
+    bool bit[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rbx[u], me, p.iou, irr);
+    if (__builtin_expect(__any(irr || p.iou.slow_only), 0)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rbx[u]), to_nbox(me), p.iou.thr);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool hit = bit[u] && (rb * 64 + r0 + u < jcol);
+      const unsigned long long word = __ballot(hit);
+      if (lane == r0 + u) mine = word;
+      mycol |= (unsigned long long)hit << (r0 + u);
+    }
+  }
+  p.mask[((long long)b * p.nb + cb) * Kp + rb * 64 + lane] = mine;
+  if (rb == cb) p.diag_t[(long long)b * Kp + jcol] = mycol;  // the scan resolves a block from its columns
+}
+
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
+    v |= ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
+// One workgroup (1024 threads) per image.  LDS: removed[nb] | keptmap[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
+__global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_nk;
+  const int b = blockIdx.x;
+  if (p.state[b * 4 + 1]) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nb = p.nb, Kp = nb * 64, R = p.R_nms;
+  int cb1 = cb0 + kBandBlocks;
+  if (cb1 > nb) cb1 = nb;
+  unsigned long long *removed = s_words;
+  unsigned long long *keptmap = s_words + nb;
+  int *kidx = reinterpret_cast<int *>(s_words + 2 * nb);
+  const unsigned long long *mask = p.mask + (long long)b * nb * Kp;
+  int nk = p.state[b * 4 + 0];
+  for (int i = tid; i < nb; i += 1024) {
+    removed[i] = p.removed[(long long)b * nb + i];
+    keptmap[i] = p.keptmap[(long long)b * nb + i];
+  }
+  for (int i = tid; i < nk; i += 1024) kidx[i] = p.kidx[(long long)b * R + i];
+  __syncthreads();
+
+  // (i) fold the kept rows of earlier bands into this band's removed words: one wave per column block
+  if (cb0 > 0) {
+    for (int cb = cb0 + w; cb < cb1; cb += 16) {
+      unsigned long long acc = 0ull;
+      const unsigned long long *col = mask + (long long)cb * Kp;
+      // words of row blocks that kept nothing were never written: they are loaded all the same (inside the workspace) and
+      // masked out, which keeps the loop free of branches so that the loads overlap
+#pragma unroll 8
+      for (int rb = 0; rb < cb0; ++rb) {
+        const unsigned long long word = col[rb * 64 + lane];
+        if ((keptmap[rb] >> lane) & 1ull) acc |= word;
+      }
+      acc = wave_or64(acc);
+      if (lane == 0) removed[cb] |= acc;
+    }
+    __syncthreads();
+  }
+
+  // (ii) the band's blocks in order.  Nothing a block needs from memory depends on the blocks before it, so the loads run
+  // one block ahead of the serial chain: the band's transposed diagonal tiles sit in LDS, the words to fold after block
+  // cb + 1 are requested while block cb is resolved.
+  unsigned long long *s_diag = reinterpret_cast<unsigned long long *>(kidx + ((R + 1) & ~1));  // [kBandBlocks * 64]
+  for (int i = tid; i < (cb1 - cb0) * 64; i += 1024) s_diag[i] = p.diag_t[(long long)b * Kp + cb0 * 64 + i];
+  unsigned long long f1n = 0ull, f2n = 0ull;
+  if (cb0 + 1 + w < cb1) f1n = mask[(long long)(cb0 + 1 + w) * Kp + cb0 * 64 + lane];
+  if (cb0 + 17 + w < cb1) f2n = mask[(long long)(cb0 + 17 + w) * Kp + cb0 * 64 + lane];
+  __syncthreads();
+  for (int cb = cb0; cb < cb1 && nk < R; ++cb) {
+    const int c1 = cb + 1 + w, c2 = c1 + 16;
+    const unsigned long long f1 = f1n, f2 = f2n;
+    f1n = f2n = 0ull;
+    if (c1 + 1 < cb1) f1n = mask[(long long)(c1 + 1) * Kp + (cb + 1) * 64 + lane];
+    if (c2 + 1 < cb1) f2n = mask[(long long)(c2 + 1) * Kp + (cb + 1) * 64 + lane];
+    if (w == 0) {
+      // Greedy order inside the block, in parallel rounds instead of one serial step per suppressing row: lane i knows
+      // which earlier rows of the block suppress it (col).  A candidate hit by a KEPT row is removed; a candidate none of
+      // whose still-undecided earlier rows suppresses it is kept (whatever those rows turn out to be, they do not touch
+      // it).  The lowest undecided candidate always falls in one of the two classes, so every round makes progress; the
+      // fixed point is the sequential greedy result, reached in (longest suppression chain) rounds -- a handful.
+      const unsigned long long col = s_diag[(cb - cb0) * 64 + lane];
+      unsigned long long und = uniform64(~removed[cb]);
+      unsigned long long keptbits = 0ull;
+      while (und != 0ull) {
+        const bool in1 = (und >> lane) & 1ull;
+        und &= ~__ballot(in1 && (col & keptbits) != 0ull);
+        const bool in2 = (und >> lane) & 1ull;
+        const unsigned long long k = __ballot(in2 && (col & und) == 0ull);
+        keptbits |= k;
+        und &= ~k;
+      }
+      int cnt = nk + __popcll(keptbits);
+      if (cnt > R) {  // the greedy scan stops at R: keep the first R - nk of the block's kept candidates
+        unsigned long long t = 0ull, bb = keptbits;
+        for (int k = nk; k < R; ++k) {
+          const unsigned long long low = bb & (0ull - bb);
+          t |= low;
+          bb ^= low;
+        }
+        keptbits = t;
+        cnt = R;
+      }
+      if ((keptbits >> lane) & 1ull) kidx[nk + __popcll(keptbits & lanemask_lt())] = cb * 64 + lane;
+      if (lane == 0) {
+        keptmap[cb] = keptbits;
+        s_kept = keptbits;
+        s_nk = cnt;
+      }
+    }
+    __syncthreads();
+    const unsigned long long kb = s_kept;
+    nk = s_nk;
+    // fold the kept rows' words into the later blocks of the band: LDS atomics (only lanes with something to add) instead
+    // of a 6-step cross-lane reduction, whose dependent ds_bpermute chain cost more than the resolve
+    const bool mine = (kb >> lane) & 1ull;
+    if (mine && f1 != 0ull) atomicOr(&removed[c1], f1);  // f1 / f2 are zero beyond the band
+    if (mine && f2 != 0ull) atomicOr(&removed[c2], f2);
+    // kBandBlocks <= 32: c1 and c2 cover every later block of the band
+    __syncthreads();
+  }
+
+  // (iii) finished (R boxes, or no candidates left): outputs; otherwise save the state for the next phase
+  const bool finished = (nk >= R) || last_phase || (cb1 >= nb);
+  if (finished) {
+    const int Ro = p.R_out;
+    for (int r = tid; r < Ro; r += 1024) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      float sc = 0.0f;
+      if (r < nk) {
+        const int ei = p.sorted_idx[(long long)b * p.K + kidx[r]];
+        const float4 a = reinterpret_cast<const float4 *>(p.anchors)[ei];
+        const float4 d = reinterpret_cast<const float4 *>(p.deltas)[(long long)b * p.N + ei];
+        o = decode_box(a, scale_deltas(d, p.v0, p.v1, p.v2, p.v3));
+        o.x = clip01(o.x);
+        o.y = clip01(o.y);
+        o.z = clip01(o.z);
+        o.w = clip01(o.w);
+        sc = p.scores[(long long)b * p.N + ei];
+      }
+      *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * Ro + r) * 4) = o;
+      if (p.out_scores) p.out_scores[(long long)b * Ro + r] = sc;
+    }
+    if (tid == 0) {
+      if (p.out_valid) p.out_valid[b] = nk;
+      p.state[b * 4 + 1] = 1;
+    }
+  } else {
+    for (int i = tid; i < nb; i += 1024) {
+      p.removed[(long long)b * nb + i] = removed[i];
+      p.keptmap[(long long)b * nb + i] = keptmap[i];
+    }
+    for (int i = tid; i < nk; i += 1024) p.kidx[(long long)b * R + i] = kidx[i];
+    if (tid == 0) p.state[b * 4 + 0] = nk;
+  }
+}
+
+struct BitmaskWorkspace {
+  int *sorted_idx;
+  int *counts;
+  float4 *pbox;
+  float2 *paf;
+  unsigned long long *mask, *diag_t, *removed, *keptmap;
+  int *state, *kidx;
+  size_t bytes;
+};
+
+static BitmaskWorkspace carve_bitmask(void *ws, int B, int K, int R) {
+  BitmaskWorkspace w;
+  unsigned char *p = reinterpret_cast<unsigned char *>(ws);
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    unsigned char *q = p ? p + off : nullptr;
+    off += round_up(bytes, 256);
+    return q;
+  };
+  const size_t nb = (size_t)(K + 63) / 64, Kp = nb * 64;
+  w.sorted_idx = reinterpret_cast<int *>(take((size_t)B * K * 4));
+  w.counts = reinterpret_cast<int *>(take((size_t)B * 4));
+  w.pbox = reinterpret_cast<float4 *>(take((size_t)B * Kp * 16));
+  w.paf = reinterpret_cast<float2 *>(take((size_t)B * Kp * 8));
+  w.mask = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * Kp * 8));
+  w.diag_t = reinterpret_cast<unsigned long long *>(take((size_t)B * Kp * 8));
+  w.removed = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * 8));
+  w.keptmap = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * 8));
+  w.state = reinterpret_cast<int *>(take((size_t)B * 16));
+  w.kidx = reinterpret_cast<int *>(take((size_t)B * (R > 0 ? R : 1) * 4));
+  w.bytes = off + 256;
+  return w;
+}
+
+// R_nms at or above which frcnn_roi_bbox takes this path (FRCNN_ROI_BBOX_BITMASK_MIN_R overrides; 0 disables).
+int roi_bbox_bitmask_min_r() {
+  if (const char *e = getenv("FRCNN_ROI_BBOX_BITMASK_MIN_R")) return atoi(e);
+  return 1024;
+}
+
+bool roi_bbox_bitmask_applies(int B, int K, int R_nms) {
+  const int min_r = roi_bbox_bitmask_min_r();
+  const long long nb = (K + 63) / 64;
+  return min_r > 0 && R_nms >= min_r && R_nms <= 16384 && B <= 65535 && nb <= 1024 &&
+         (size_t)(2 * nb * 8 + (size_t)R_nms * 4 + 8 + kBandBlocks * 64 * 8) <= 150 * 1024;
+}
+
+size_t roi_bbox_bitmask_workspace_bytes(int B, int K, int R_nms) { return carve_bitmask(nullptr, B, K, R_nms).bytes; }
+
+int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
+                            int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
+                            int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+  BitmaskWorkspace w = carve_bitmask(workspace, B, K, R_nms);
+  if (!workspace || !aligned_to(workspace, 256) || workspace_bytes < w.bytes)
+    return set_error(FRCNN_EINVAL, "roi_bbox: workspace must be non-null, 256-byte aligned and >= %zu bytes (got %zu)", w.bytes,
+                     workspace_bytes);
+  ScoreSource ss;
+  ss.scores = scores;
+  ss.stride_b = N;
+  ss.elem_stride = 1;
+  ss.mask_bg = 0;
+  ss.L = 0;
+  int rc = launch_sort_select(ss, B, 1, N, K, false, 0.0f, w.sorted_idx, nullptr, w.counts, K, stream);
+  if (rc) return rc;
+  BitmaskParams p;
+  p.deltas = deltas;
+  p.scores = scores;
+  p.anchors = anchors;
+  p.v0 = variances[0];
+  p.v1 = variances[1];
+  p.v2 = variances[2];
+  p.v3 = variances[3];
+  p.N = N;
+  p.K = K;
+  p.R_nms = R_nms;
+  p.R_out = R_out;
+  p.iou = make_iou_thr(iou_thr);
+  p.score_thr = -__builtin_huge_valf();
+  p.nb = (K + 63) / 64;
+  p.sorted_idx = w.sorted_idx;
+  p.pbox = w.pbox;
+  p.paf = w.paf;
+  p.mask = w.mask;
+  p.diag_t = w.diag_t;
+  p.removed = w.removed;
+  p.keptmap = w.keptmap;
+  p.state = w.state;
+  p.kidx = w.kidx;
+  p.out_boxes = out_boxes;
+  p.out_scores = out_scores;
+  p.out_valid = out_valid;
+  hipLaunchKernelGGL(bm_prepare_kernel, dim3((unsigned)((p.nb + 3) / 4), (unsigned)B), dim3(256), 0, stream, p);
+  rc = check_launch("roi_bbox (bitmask prepare)");
+  if (rc) return rc;
+  const size_t lds = (size_t)2 * p.nb * 8 + (size_t)((R_nms + 1) & ~1) * 4 + (size_t)kBandBlocks * 64 * 8;
+  auto scan = bm_scan_kernel;
+  if (lds > 48 * 1024) {
+    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                   "roi_bbox: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  for (int cb0 = 0; cb0 < p.nb; cb0 += kBandBlocks) {
+    const int cb1 = (cb0 + kBandBlocks < p.nb) ? cb0 + kBandBlocks : p.nb;
+    hipLaunchKernelGGL(bm_tiles_kernel, dim3((unsigned)(cb1 - cb0), (unsigned)((cb1 + 3) / 4), (unsigned)B), dim3(256), 0, stream, p,
+                       cb0);
+    rc = check_launch("roi_bbox (bitmask tiles)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(scan, dim3((unsigned)B), dim3(1024), lds, stream, p, cb0, cb1 >= p.nb ? 1 : 0);
+    rc = check_launch("roi_bbox (bitmask scan)");
+    if (rc) return rc;
+  }
+  return FRCNN_OK;
+}
+
+}  // namespace frcnn
