@@ -278,6 +278,13 @@ def test_roi_bbox_config2(pkg):
     assert_bits(got, want, "RoIBBox cfg2")
 
 
+def test_roi_bbox_fused_kernel_large_r(pkg, monkeypatch):
+    """The one-workgroup-per-image kernel at a post_nms_topn the bitmask schedule would otherwise take."""
+    monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "0")
+    got, want = _roi_bbox_case(pkg, 2, 2, 31, 6000, 2000, mode="training")
+    assert_bits(got, want, "RoIBBox fused kernel, R=2000")
+
+
 def test_roi_bbox_train_mode_and_ties(pkg):
     got, want = _roi_bbox_case(pkg, 2, 4, 31, 6000, 2000, mode="training")
     assert_bits(got, want, "RoIBBox cfg3-like (vgg16 grid, R=2000)")
@@ -294,6 +301,8 @@ def test_roi_bbox_stress_shape(pkg):
 def test_roi_bbox_unfused_path(pkg, monkeypatch):
     """The generic sort -> NMS pipeline behind frcnn_roi_bbox (taken when the fused kernel's LDS budget is exceeded)."""
     monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+    got, want = _roi_bbox_case(pkg, 7, 2, 16, 2304, 1500, mode="training")
+    assert_bits(got, want, "RoIBBox unfused large R")
     got, want = _roi_bbox_case(pkg, 5, 4, 32, 6000, 300)
     assert_bits(got, want, "RoIBBox unfused cfg2")
     got, want = _roi_bbox_case(pkg, 6, 2, 63, 12000, 300)
@@ -301,7 +310,7 @@ def test_roi_bbox_unfused_path(pkg, monkeypatch):
 
 
 def test_roi_bbox_bitmask_path(pkg, monkeypatch):
-    """The whole-chip bitmask schedule (taken for post_nms_topn >= 1024), forced on every shape: one and several phases,
+    """The whole-chip bitmask schedule (taken for post_nms_topn >= 512), forced on every shape: one and several phases,
     early finish, exhausted candidates, ties, K not a multiple of 64, R larger than K."""
     monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "1")
     for args, kw in (((10, 2, 8, 64, 16), {}), ((11, 2, 16, 2304, 300), {}), ((12, 4, 32, 6000, 300), {}),

@@ -3,16 +3,17 @@
 //
 // Replaces models/faster_rcnn.py:153-164 like proposal.hip; same results, different schedule.  The fused
 // one-workgroup-per-image kernel (proposal.hip) tests every 128-candidate chunk against the kept list on ONE CU: at
-// R = 2000 that is ~3 M pair tests per image, 1.6 ms per 16 images.  Here:
+// R = 2000 that is ~3 M pair tests per image, 1.6 ms per 16 images (0.38 ms with this schedule).  Here:
 //   1. sort_select orders the top-K candidates (score desc, index asc) -- sort_select.hip;
 //   2. `bm_prepare_kernel` decodes them once into packed boxes (corner-normalised box, area, flags);
 //   3. per PHASE (a band of kBandBlocks 64-candidate column blocks, i.e. 2048 candidates):
-//      `bm_tiles_kernel` (whole grid): for every 64x64 tile (row block rb <= column block cb of the band) the
-//         suppression words mask[cb][row] = ballot over the 64 column boxes of "IoU(row, col) > thr and row before col".
-//         Row blocks of EARLIER bands in which nothing was kept are skipped (their rows can suppress nobody);
-//      `bm_scan_kernel` (one workgroup per image): folds the kept rows of earlier bands into the band's `removed`
-//         words, then walks the band's blocks in order: wave 0 resolves the greedy order inside a block on scalar
-//         registers (as nms_core.hpp), the other waves OR the kept rows' words into the later blocks of the band.
+//      `bm_tiles_kernel` (whole grid): 64x64 tiles of suppression words = ballot over the 64 column boxes of
+//         "IoU(row, col) > thr and row before col".  Rows are (a) the boxes KEPT in earlier bands, compacted (a box that
+//         was suppressed can suppress nobody, so only ~R of the cb0*64 earlier candidates are rows), and (b) the band's own
+//         candidates up to the column's block (undecided yet);
+//      `bm_scan_kernel` (one workgroup per image): ORs the (a) words into the band's `removed` words, then walks the
+//         band's blocks in order: wave 0 resolves the greedy order inside a block in parallel rounds from the block's
+//         transposed diagonal tile, all waves fold the kept rows' (b) words into the later blocks of the band.
 //      An image that has its R boxes (or runs out of candidates) writes its outputs and marks itself done; later phases
 //      return at once for it, so the work is proportional to the candidates actually consumed, in bands of 2048.
 // All state between kernels lives in the caller's workspace; nothing synchronises with the host.
@@ -38,10 +39,11 @@ struct BitmaskParams {
   const int *sorted_idx;        // (B,K)
   float4 *pbox;                 // (B, nb*64)
   float2 *paf;                  // (B, nb*64)   (area, flags as int bits)
-  unsigned long long *mask;     // (B, nb, nb*64)   mask[cb][row]
+  int Rx;                       // R_nms rounded up to 64: row capacity of xmask
+  unsigned long long *xmask;    // (B, nb, Rx)              xmask[cb][kept position]: rows = boxes kept in earlier bands
+  unsigned long long *mask;     // (B, nb, kBandBlocks*64)  mask[cb][row - first row of cb's band]: rows of the same band
   unsigned long long *diag_t;   // (B, nb*64)  transposed diagonal tiles: bit r of diag_t[col] = "row r of col's block suppresses col"
   unsigned long long *removed;  // (B, nb)
-  unsigned long long *keptmap;  // (B, nb)
   int *state;                   // (B, 4): nk, done
   int *kidx;                    // (B, R_nms) sorted positions of the kept boxes
   float *out_boxes;             // (B,R_out,4)
@@ -75,7 +77,6 @@ __global__ __launch_bounds__(256) void bm_prepare_kernel(BitmaskParams p) {
   const unsigned long long badw = __ballot(bad);
   if (lane == 0) {
     p.removed[(long long)b * p.nb + blk] = badw;
-    p.keptmap[(long long)b * p.nb + blk] = 0ull;
     if (blk == 0) {
       p.state[b * 4 + 0] = 0;
       p.state[b * 4 + 1] = 0;
@@ -83,29 +84,49 @@ __global__ __launch_bounds__(256) void bm_prepare_kernel(BitmaskParams p) {
   }
 }
 
-// grid (band column blocks, ceil(row blocks / 4), B), block 256: wave w <-> row block 4*blockIdx.y + w.
-__global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0) {
+// grid (band column blocks, ceil((gx + band blocks) / 4), B), block 256: wave w <-> row group g = 4*blockIdx.y + w.
+// Groups g < gx are 64 kept boxes of earlier bands (gx = host-side bound on their number / 64); the others are the band's
+// own blocks rb = cb0 + g - gx.
+__global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0, int gx) {
   __shared__ float4 s_box[4][64];
   __shared__ float2 s_af[4][64];
   const int b = blockIdx.z;
   if (p.state[b * 4 + 1]) return;  // image finished in an earlier phase
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cb = cb0 + blockIdx.x;
-  const int rb = blockIdx.y * 4 + w;
-  if (cb >= p.nb || rb > cb) return;  // wave-uniform
-  // rows of an earlier band that kept nothing cannot suppress: the scan never reads their words
-  if (rb < cb0 && p.keptmap[(long long)b * p.nb + rb] == 0ull) return;
+  const int g = blockIdx.y * 4 + w;
+  if (cb >= p.nb) return;
   const int Kp = p.nb * 64;
   const float4 *pbox = p.pbox + (long long)b * Kp;
   const float2 *paf = p.paf + (long long)b * Kp;
-  s_box[w][lane] = pbox[rb * 64 + lane];
-  s_af[w][lane] = paf[rb * 64 + lane];
+  const bool cross = g < gx;
+  int rb = 0, row_pos;  // row_pos: this lane's row as a position in the sorted order
+  if (cross) {
+    const int nk_prev = p.state[b * 4 + 0];
+    if (g * 64 >= nk_prev) return;  // wave-uniform
+    const int kpos = g * 64 + lane;
+    row_pos = (kpos < nk_prev) ? p.kidx[(long long)b * p.R_nms + kpos] : -1;
+  } else {
+    rb = cb0 + (g - gx);
+    if (rb > cb) return;  // wave-uniform
+    row_pos = rb * 64 + lane;
+  }
+  float4 rbox = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 raf = make_float2(0.f, 0.f);  // flags 0: fails the area guard, overlaps nobody
+  if (row_pos >= 0) {
+    rbox = pbox[row_pos];
+    raf = paf[row_pos];
+  }
+  s_box[w][lane] = rbox;
+  s_af[w][lane] = raf;
   const int jcol = cb * 64 + lane;
   const PBox me = load_pbox(pbox, paf, jcol);
   // wave-private LDS rows: LDS operations of a wave complete in order; keep the compiler from hoisting the reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // rows of earlier bands all precede the column; inside the band only rows before the column count
+  const int first_row = cross ? -64 : rb * 64;
   unsigned long long mine = 0ull, mycol = 0ull;
   for (int r0 = 0; r0 < 64; r0 += 4) {
     PBox rbx[4];
@@ -121,14 +142,18 @@ __global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0)
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const bool hit = bit[u] && (rb * 64 + r0 + u < jcol);
+      const bool hit = bit[u] && (first_row + r0 + u < jcol);
       const unsigned long long word = __ballot(hit);
       if (lane == r0 + u) mine = word;
       mycol |= (unsigned long long)hit << (r0 + u);
     }
   }
-  p.mask[((long long)b * p.nb + cb) * Kp + rb * 64 + lane] = mine;
-  if (rb == cb) p.diag_t[(long long)b * Kp + jcol] = mycol;  // the scan resolves a block from its columns
+  if (cross) {
+    p.xmask[((long long)b * p.nb + cb) * p.Rx + g * 64 + lane] = mine;
+  } else {
+    p.mask[((long long)b * p.nb + cb) * (kBandBlocks * 64) + (rb - cb0) * 64 + lane] = mine;
+    if (rb == cb) p.diag_t[(long long)b * Kp + jcol] = mycol;  // the scan resolves a block from its columns
+  }
 }
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
@@ -141,7 +166,7 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
   return v;
 }
 
-// One workgroup (1024 threads) per image.  LDS: removed[nb] | keptmap[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
+// One workgroup (1024 threads) per image.  LDS: removed[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
 __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
   __shared__ unsigned long long s_kept;
@@ -152,30 +177,23 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
   const int nb = p.nb, Kp = nb * 64, R = p.R_nms;
   int cb1 = cb0 + kBandBlocks;
   if (cb1 > nb) cb1 = nb;
+  constexpr int BW = kBandBlocks * 64;  // rows of a band
   unsigned long long *removed = s_words;
-  unsigned long long *keptmap = s_words + nb;
-  int *kidx = reinterpret_cast<int *>(s_words + 2 * nb);
-  const unsigned long long *mask = p.mask + (long long)b * nb * Kp;
+  int *kidx = reinterpret_cast<int *>(s_words + nb);
+  const unsigned long long *mask = p.mask + (long long)b * nb * BW;
   int nk = p.state[b * 4 + 0];
-  for (int i = tid; i < nb; i += 1024) {
-    removed[i] = p.removed[(long long)b * nb + i];
-    keptmap[i] = p.keptmap[(long long)b * nb + i];
-  }
+  for (int i = tid; i < nb; i += 1024) removed[i] = p.removed[(long long)b * nb + i];
   for (int i = tid; i < nk; i += 1024) kidx[i] = p.kidx[(long long)b * R + i];
   __syncthreads();
 
-  // (i) fold the kept rows of earlier bands into this band's removed words: one wave per column block
-  if (cb0 > 0) {
+  // (i) the boxes kept in earlier bands suppress into this band: one wave per column block ORs their words
+  if (cb0 > 0 && nk > 0) {
+    const unsigned long long *xm = p.xmask + (long long)b * nb * p.Rx;
     for (int cb = cb0 + w; cb < cb1; cb += 16) {
       unsigned long long acc = 0ull;
-      const unsigned long long *col = mask + (long long)cb * Kp;
-      // words of row blocks that kept nothing were never written: they are loaded all the same (inside the workspace) and
-      // masked out, which keeps the loop free of branches so that the loads overlap
-#pragma unroll 8
-      for (int rb = 0; rb < cb0; ++rb) {
-        const unsigned long long word = col[rb * 64 + lane];
-        if ((keptmap[rb] >> lane) & 1ull) acc |= word;
-      }
+      const unsigned long long *col = xm + (long long)cb * p.Rx;
+#pragma unroll 4
+      for (int k0 = 0; k0 < nk; k0 += 64) acc |= col[k0 + lane];  // lanes past nk hold zero words (written by the tiles)
       acc = wave_or64(acc);
       if (lane == 0) removed[cb] |= acc;
     }
@@ -188,15 +206,15 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
   unsigned long long *s_diag = reinterpret_cast<unsigned long long *>(kidx + ((R + 1) & ~1));  // [kBandBlocks * 64]
   for (int i = tid; i < (cb1 - cb0) * 64; i += 1024) s_diag[i] = p.diag_t[(long long)b * Kp + cb0 * 64 + i];
   unsigned long long f1n = 0ull, f2n = 0ull;
-  if (cb0 + 1 + w < cb1) f1n = mask[(long long)(cb0 + 1 + w) * Kp + cb0 * 64 + lane];
-  if (cb0 + 17 + w < cb1) f2n = mask[(long long)(cb0 + 17 + w) * Kp + cb0 * 64 + lane];
+  if (cb0 + 1 + w < cb1) f1n = mask[(long long)(cb0 + 1 + w) * BW + lane];
+  if (cb0 + 17 + w < cb1) f2n = mask[(long long)(cb0 + 17 + w) * BW + lane];
   __syncthreads();
   for (int cb = cb0; cb < cb1 && nk < R; ++cb) {
     const int c1 = cb + 1 + w, c2 = c1 + 16;
     const unsigned long long f1 = f1n, f2 = f2n;
     f1n = f2n = 0ull;
-    if (c1 + 1 < cb1) f1n = mask[(long long)(c1 + 1) * Kp + (cb + 1) * 64 + lane];
-    if (c2 + 1 < cb1) f2n = mask[(long long)(c2 + 1) * Kp + (cb + 1) * 64 + lane];
+    if (c1 + 1 < cb1) f1n = mask[(long long)(c1 + 1) * BW + (cb + 1 - cb0) * 64 + lane];
+    if (c2 + 1 < cb1) f2n = mask[(long long)(c2 + 1) * BW + (cb + 1 - cb0) * 64 + lane];
     if (w == 0) {
       // Greedy order inside the block, in parallel rounds instead of one serial step per suppressing row: lane i knows
       // which earlier rows of the block suppress it (col).  A candidate hit by a KEPT row is removed; a candidate none of
@@ -227,7 +245,6 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
       }
       if ((keptbits >> lane) & 1ull) kidx[nk + __popcll(keptbits & lanemask_lt())] = cb * 64 + lane;
       if (lane == 0) {
-        keptmap[cb] = keptbits;
         s_kept = keptbits;
         s_nk = cnt;
       }
@@ -270,10 +287,7 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
       p.state[b * 4 + 1] = 1;
     }
   } else {
-    for (int i = tid; i < nb; i += 1024) {
-      p.removed[(long long)b * nb + i] = removed[i];
-      p.keptmap[(long long)b * nb + i] = keptmap[i];
-    }
+    for (int i = tid; i < nb; i += 1024) p.removed[(long long)b * nb + i] = removed[i];
     for (int i = tid; i < nk; i += 1024) p.kidx[(long long)b * R + i] = kidx[i];
     if (tid == 0) p.state[b * 4 + 0] = nk;
   }
@@ -284,7 +298,7 @@ struct BitmaskWorkspace {
   int *counts;
   float4 *pbox;
   float2 *paf;
-  unsigned long long *mask, *diag_t, *removed, *keptmap;
+  unsigned long long *xmask, *mask, *diag_t, *removed;
   int *state, *kidx;
   size_t bytes;
 };
@@ -303,10 +317,11 @@ static BitmaskWorkspace carve_bitmask(void *ws, int B, int K, int R) {
   w.counts = reinterpret_cast<int *>(take((size_t)B * 4));
   w.pbox = reinterpret_cast<float4 *>(take((size_t)B * Kp * 16));
   w.paf = reinterpret_cast<float2 *>(take((size_t)B * Kp * 8));
-  w.mask = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * Kp * 8));
+  const size_t Rx = (size_t)((R > 0 ? R : 1) + 63) / 64 * 64;
+  w.xmask = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * Rx * 8));
+  w.mask = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * kBandBlocks * 64 * 8));
   w.diag_t = reinterpret_cast<unsigned long long *>(take((size_t)B * Kp * 8));
   w.removed = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * 8));
-  w.keptmap = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * 8));
   w.state = reinterpret_cast<int *>(take((size_t)B * 16));
   w.kidx = reinterpret_cast<int *>(take((size_t)B * (R > 0 ? R : 1) * 4));
   w.bytes = off + 256;
@@ -316,14 +331,14 @@ static BitmaskWorkspace carve_bitmask(void *ws, int B, int K, int R) {
 // R_nms at or above which frcnn_roi_bbox takes this path (FRCNN_ROI_BBOX_BITMASK_MIN_R overrides; 0 disables).
 int roi_bbox_bitmask_min_r() {
   if (const char *e = getenv("FRCNN_ROI_BBOX_BITMASK_MIN_R")) return atoi(e);
-  return 1024;
+  return 512;  // measured crossover at B=16, K=6000: R=500 149 us either way; R=700 302 (fused) / 153; R=1500 1653 / 368
 }
 
 bool roi_bbox_bitmask_applies(int B, int K, int R_nms) {
   const int min_r = roi_bbox_bitmask_min_r();
   const long long nb = (K + 63) / 64;
   return min_r > 0 && R_nms >= min_r && R_nms <= 16384 && B <= 65535 && nb <= 1024 &&
-         (size_t)(2 * nb * 8 + (size_t)R_nms * 4 + 8 + kBandBlocks * 64 * 8) <= 150 * 1024;
+         (size_t)(nb * 8 + (size_t)R_nms * 4 + 8 + kBandBlocks * 64 * 8) <= 150 * 1024;
 }
 
 size_t roi_bbox_bitmask_workspace_bytes(int B, int K, int R_nms) { return carve_bitmask(nullptr, B, K, R_nms).bytes; }
@@ -361,10 +376,11 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   p.sorted_idx = w.sorted_idx;
   p.pbox = w.pbox;
   p.paf = w.paf;
+  p.Rx = (R_nms + 63) / 64 * 64;
+  p.xmask = w.xmask;
   p.mask = w.mask;
   p.diag_t = w.diag_t;
   p.removed = w.removed;
-  p.keptmap = w.keptmap;
   p.state = w.state;
   p.kidx = w.kidx;
   p.out_boxes = out_boxes;
@@ -373,7 +389,7 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   hipLaunchKernelGGL(bm_prepare_kernel, dim3((unsigned)((p.nb + 3) / 4), (unsigned)B), dim3(256), 0, stream, p);
   rc = check_launch("roi_bbox (bitmask prepare)");
   if (rc) return rc;
-  const size_t lds = (size_t)2 * p.nb * 8 + (size_t)((R_nms + 1) & ~1) * 4 + (size_t)kBandBlocks * 64 * 8;
+  const size_t lds = (size_t)p.nb * 8 + (size_t)((R_nms + 1) & ~1) * 4 + (size_t)kBandBlocks * 64 * 8;
   auto scan = bm_scan_kernel;
   if (lds > 48 * 1024) {
     rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -382,8 +398,11 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   }
   for (int cb0 = 0; cb0 < p.nb; cb0 += kBandBlocks) {
     const int cb1 = (cb0 + kBandBlocks < p.nb) ? cb0 + kBandBlocks : p.nb;
-    hipLaunchKernelGGL(bm_tiles_kernel, dim3((unsigned)(cb1 - cb0), (unsigned)((cb1 + 3) / 4), (unsigned)B), dim3(256), 0, stream, p,
-                       cb0);
+    // at most min(R_nms, cb0 * 64) boxes were kept before this band
+    const int kept_bound = (R_nms < cb0 * 64) ? R_nms : cb0 * 64;
+    const int gx = (kept_bound + 63) / 64;
+    hipLaunchKernelGGL(bm_tiles_kernel, dim3((unsigned)(cb1 - cb0), (unsigned)((gx + (cb1 - cb0) + 3) / 4), (unsigned)B), dim3(256),
+                       0, stream, p, cb0, gx);
     rc = check_launch("roi_bbox (bitmask tiles)");
     if (rc) return rc;
     hipLaunchKernelGGL(scan, dim3((unsigned)B), dim3(1024), lds, stream, p, cb0, cb1 >= p.nb ? 1 : 0);
