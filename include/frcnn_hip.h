@@ -98,7 +98,10 @@ int frcnn_combined_nms(const float *boxes, const float *scores, int B, int n, in
 /* ---- layers -------------------------------------------------------------------------- */
 /* models/faster_rcnn.py:130-166 RoIBBox.call, fused: variance scale + decode + per-image top-K
  * + single-class greedy NMS + clip + zero pad.  deltas (B,N,4), scores (B,N), anchors (N,4),
- * variances: host, 4 floats.  out_boxes (B,R,4); out_scores (B,R) and out_valid (B) optional. */
+ * variances: host, 4 floats.  out_boxes (B,R,4); out_scores (B,R) and out_valid (B) optional.
+ * Schedules (same results): one workgroup per image for R < 512, the whole-chip bitmask NMS from
+ * there on (training's train_nms_topn); the latter keeps its tiles in the workspace, which is why the
+ * workspace query grows with K*R (about 3 MB per image at K=6000, R=2000). */
 size_t frcnn_roi_bbox_workspace_bytes(int B, int N, int K, int R);
 int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchors,
                    const float *variances, int B, int N, int K, int R, float iou_threshold,
