@@ -214,7 +214,7 @@ def main() -> None:
         crop_bytes = crop_bytes_per_image(cfg) * cfg["B"]
         achieved = crop_bytes / (crop_ms * 1e-3) / 1e9
         result = {
-            "metric": "images/sec through RPN decode+NMS+RoIPool+class NMS (bs16, 500^2); HBM GB/s",
+            "metric": "images/sec through RPN decode+NMS+RoIPool+class NMS (bs16, 500\u00b2); HBM GB/s",
             "value": round(value, 1),
             "unit": "images/s",
             "n_gpus": world,
