@@ -620,6 +620,24 @@ def test_generators_prefetch_targets_on_side_stream(pkg):
         next(pkg.train_utils.rpn_generator([], anchors, hp))
 
 
+def test_config1_batch1_full_path(pkg):
+    """BASELINE config 1 shape: mobilenet_v2, 500x500, batch 1 -- RoIBBox -> RoIPooling -> Decoder against the oracle."""
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp["total_labels"] = 21
+    anchors = oracle.generate_anchors(hp)
+    deltas, scores = synth.rpn_outputs(21, 1, 32)
+    fm = synth.feature_map(21, 1, 32, 576)
+    hd, hpb = synth.head_outputs(21, 1, 300, 21)
+    rois = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+    pooled = pkg.faster_rcnn.RoIPooling(hp)([dev(fm), rois])
+    dets = pkg.faster_rcnn.Decoder(hp["variances"], 21)([rois, dev(hd), dev(hpb)])
+    wrois = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], 6000, 300, 0.7)
+    assert_bits(rois, wrois, "cfg1 rois")
+    assert_bits(pooled, oracle.roi_pooling(fm, wrois, (7, 7)), "cfg1 pooled")
+    for g, w, name in zip(dets, oracle.decoder(wrois, hd, hpb, hp["variances"], 21), ("boxes", "labels", "scores")):
+        assert_bits(g, w, f"cfg1 Decoder {name}")
+
+
 # ------------------------------------------------------------------------------------------------
 # stage pipeline over streams
 # ------------------------------------------------------------------------------------------------
