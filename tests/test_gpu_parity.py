@@ -682,3 +682,122 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable):
         for name, want in (("roi_bboxes", rois), ("roi_pooled", pooled), ("bboxes", boxes), ("labels", labels), ("scores", sc)):
             assert_bits(got[i][name], want, f"pipeline batch {i} {name} vs oracle")
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
+
+
+# ------------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties (the oracle is too slow there)
+# ------------------------------------------------------------------------------------------------
+def _roi_bbox_raw(pkg, deltas, scores, anchors, hp, K, R):
+    """frcnn_roi_bbox through the C ABI with scores and valid counts (the layer returns boxes only)."""
+    lib = pkg._lib.lib()
+    B, N = scores.shape[0], anchors.shape[0]
+    out = torch.empty((B, R, 4), dtype=torch.float32, device="cuda")
+    sc = torch.empty((B, R), dtype=torch.float32, device="cuda")
+    valid = torch.empty((B,), dtype=torch.int32, device="cuda")
+    ws = torch.empty(lib.frcnn_roi_bbox_workspace_bytes(B, N, K, R), dtype=torch.uint8, device="cuda")
+    pkg._lib.check(lib.frcnn_roi_bbox(deltas.data_ptr(), scores.data_ptr(), anchors.data_ptr(), pkg._lib.float4(hp["variances"]),
+                                      B, N, K, R, float(hp["nms_iou_threshold"]), out.data_ptr(), sc.data_ptr(), valid.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    return out, sc, valid
+
+
+def _check_nms_properties(boxes, sc, valid, thr):
+    """Rows are score-ordered and clipped, padding is zero, and no two kept boxes overlap above the threshold."""
+    B, R, _ = boxes.shape
+    idx = torch.arange(R, device=boxes.device)[None, :]
+    live = idx < valid[:, None]
+    assert (boxes[~live] == 0).all() and (sc[~live] == 0).all()
+    assert ((boxes >= 0) & (boxes <= 1)).all()
+    d = sc[:, 1:] - sc[:, :-1]
+    assert (d[live[:, 1:]] <= 0).all(), "scores must be non-increasing over the valid rows"
+    y1, x1, y2, x2 = boxes.unbind(-1)
+    area = (y2 - y1) * (x2 - x1)
+    ih = (torch.minimum(y2[:, :, None], y2[:, None, :]) - torch.maximum(y1[:, :, None], y1[:, None, :])).clamp(min=0)
+    iw = (torch.minimum(x2[:, :, None], x2[:, None, :]) - torch.maximum(x1[:, :, None], x1[:, None, :])).clamp(min=0)
+    inter = ih * iw
+    iou = inter / (area[:, :, None] + area[:, None, :] - inter)
+    pair = live[:, :, None] & live[:, None, :] & (idx[:, :, None] < idx[:, None, :]) & (area[:, :, None] > 0) & (area[:, None, :] > 0)
+    # the kernel tests the UNCLIPPED boxes; clipping can only change the IoU of boxes that left the image, so allow a margin
+    inside = ((boxes > 0) & (boxes < 1)).all(-1)
+    strict = pair & inside[:, :, None] & inside[:, None, :]
+    assert not (iou[strict] > thr * (1 + 1e-5)).any(), "two kept boxes overlap above the NMS threshold"
+
+
+def test_full_size_config3_shard_properties(pkg):
+    """BASELINE config 3 per-GPU shard: vgg16 grid (8649 anchors, 512 channels), B=16, train mode, post_nms 2000."""
+    hp = pkg.train_utils.get_hyper_params("vgg16", train_nms_topn=2000)
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    deltas, scores = synth.rpn_outputs(31, 16, 31)
+    boxes, sc, valid = _roi_bbox_raw(pkg, dev(deltas).reshape(16, -1, 4), dev(scores).reshape(16, -1), anchors, hp, 6000, 2000)
+    assert (valid > 0).all()
+    _check_nms_properties(boxes, sc, valid, hp["nms_iou_threshold"])
+    layer_out = pkg.faster_rcnn.RoIBBox(anchors, "training", hp)([dev(deltas), dev(scores)])
+    assert torch.equal(layer_out, boxes)
+    # crop_and_resize is linear in the feature map: scaling by 2 is exact, and channels are independent
+    fm = dev(synth.feature_map(31, 16, 31, 512))
+    pool = pkg.faster_rcnn.RoIPooling(hp)
+    pooled = pool([fm, boxes])
+    assert pooled.shape == (16, 2000, 7, 7, 512)
+    assert torch.equal(pool([fm * 2, boxes]), pooled * 2)
+    perm = torch.randperm(512, device="cuda")
+    assert torch.equal(pool([fm[..., perm].contiguous(), boxes]), pooled[..., perm])
+    # a zero-padded RoI samples pixel (0,0) everywhere; a whole-image RoI returns the corners exactly
+    probe = boxes.clone()
+    probe[:, 0] = torch.tensor([0.0, 0.0, 1.0, 1.0], device="cuda")
+    probe[:, 1] = 0.0
+    p2 = pool([fm, probe])
+    assert torch.equal(p2[:, 0, 0, 0], fm[:, 0, 0]) and torch.equal(p2[:, 0, 6, 6], fm[:, 30, 30])
+    assert torch.equal(p2[:, 1], fm[:, 0, 0][:, None, None, :].expand(-1, 7, 7, -1))
+
+
+def test_full_size_config4_properties(pkg):
+    """BASELINE config 4: RPN targets, B=64, 9216 anchors x 100 gt boxes."""
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    N = anchors.shape[0]
+    gt, labels = synth.gt_boxes(41, 64, 100)
+    gt_t, lab_t = dev(gt), dev(labels)
+    iou = pkg.bbox_utils.generate_iou_map(anchors, gt_t)
+    # the formula is symmetric in its two boxes: swapping the roles gives the transposed map exactly
+    # (the second operand is staged in LDS: at most 3072 boxes, so the swap uses the first 3072 anchors)
+    swapped = pkg.bbox_utils.generate_iou_map(gt_t, anchors[None, :3072].expand(64, -1, -1).contiguous())
+    assert torch.equal(torch.nan_to_num(iou[:, :3072], nan=-1.0), torch.nan_to_num(swapped.transpose(1, 2), nan=-1.0))
+    assert ((iou >= 0) & (iou <= 1)).all()
+    assert (iou[dev(labels < 0)[:, None, :].expand(-1, N, -1)] == 0).all()  # zero-padded gts never overlap
+    rp, rn = synth.sampling_ints(41, 64, N)
+    deltas, lab = pkg.train_utils.calculate_rpn_actual_outputs(anchors, gt_t, lab_t, hp, random_masks=(dev(rp), dev(rn)))
+    lab = lab.reshape(64, N)
+    pos, neg = (lab == 1), (lab == 0)
+    assert (pos.sum(1) <= 128).all() and ((pos.sum(1) + neg.sum(1)) == 256).all()
+    miou = iou.max(2).values
+    assert (miou[neg] < 0.3).all()
+    # a positive either exceeds 0.7 or attains the column maximum of a valid gt (clipped anchors coincide, so the
+    # maximum can be attained by several anchors; the kernel forces the first of them)
+    col_best = ((iou == iou.max(1, keepdim=True).values) & dev(labels >= 0)[:, None, :]).any(2)
+    assert (miou[pos] > 0.7).logical_or(col_best[pos]).all()
+    assert (deltas[~pos] == 0).all() and torch.isfinite(deltas).all()
+    # the fused reductions agree with reductions of the materialised map
+    m2, a2, s2 = pkg.eval_utils.match_predictions(anchors[None].expand(64, -1, -1).contiguous(), gt_t)
+    ar = torch.arange(100, device="cuda")[None, None, :]
+    first_max = torch.where(iou == miou[..., None], ar, 1000).min(2).values  # first maximal index, ties included
+    assert torch.equal(m2, miou) and torch.equal(a2.long(), first_max)
+
+
+def test_full_size_config5_shard_properties(pkg):
+    """BASELINE config 5 per-GPU shard: 1000x1000 images (63x63 grid, 35721 anchors), pre_nms_topn 12000, B=16."""
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", img_size=1000, feature_map_shape=63, pre_nms_topn=12000)
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    assert anchors.shape[0] == 35721
+    deltas, scores = synth.rpn_outputs(51, 16, 63)
+    boxes, sc, valid = _roi_bbox_raw(pkg, dev(deltas).reshape(16, -1, 4), dev(scores).reshape(16, -1), anchors, hp, 12000, 300)
+    assert (valid == 300).all()
+    _check_nms_properties(boxes, sc, valid, hp["nms_iou_threshold"])
+    top_v, top_i = pkg.bbox_utils.top_k(dev(scores).reshape(16, -1), 12000)
+    assert (top_v[:, 1:] <= top_v[:, :-1]).all() and torch.equal(top_v[:, 0], sc[:, 0])  # the best candidate is always kept
+    assert torch.equal(torch.gather(dev(scores).reshape(16, -1), 1, top_i.long()), top_v)
+    fm = dev(synth.feature_map(51, 16, 63, 576))  # 9.1 MB per image: the channel-slice crop kernel
+    pool = pkg.faster_rcnn.RoIPooling(hp)
+    pooled = pool([fm, boxes])
+    assert torch.equal(pool([fm * 2, boxes]), pooled * 2)
+    assert (pooled >= 0).all() and (pooled.amax((1, 2, 3)) <= fm.amax((1, 2))).all()  # convex combinations of the taps
