@@ -192,6 +192,21 @@ __device__ __forceinline__ float4 encode_box(float4 bx, float4 g) {
   return o;
 }
 
+// ---- bare hardware max / min ------------------------------------------------------------------------
+// __builtin_fmaxf / fminf lower to llvm.maxnum / minnum, which in IEEE mode canonicalise both inputs first (a v_max_f32
+// x, x each): three instructions per max.  Where the caller has established that neither operand is NaN the bare
+// v_max_f32 / v_min_f32 give the same value (up to the sign of a zero).
+__device__ __forceinline__ float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // ---- NMS-internal IoU test (TF non_max_suppression_op.cc IOUGreaterThanThreshold) ------------
 struct NBox {  // corner-normalised box + its area
   float ymin, xmin, ymax, xmax, area;

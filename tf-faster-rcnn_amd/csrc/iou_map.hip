@@ -21,17 +21,6 @@ namespace frcnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float hw_max(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float hw_min(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 // utils/bbox_utils.py:154-160 for one pair; barea/garea from :152-153.
 // NONAN: the caller has established that no coordinate of either box is NaN.  Then the reference's maximum / minimum
 // (written as the ternaries below, which is how they treat NaN) equal the hardware v_max_f32 / v_min_f32 up to the sign of

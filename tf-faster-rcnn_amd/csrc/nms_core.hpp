@@ -15,7 +15,7 @@ static const int kMaxKept = 5000;  // kept-list capacity in LDS (28 B per entry)
 //   t = fl(thr * uni) is within 2^-24 (relative) of thr * uni and mid is within 2^-24 of thr, so
 //   inter > t * (1 + 2^-21)  =>  true,      inter < t * (1 - 2^-21)  =>  false,
 // and only the pairs inside that 2^-20-wide band (about one in a million near-threshold pairs), irregular
-// operands (uni outside [1e-30, 1e30], non-finite coordinates) or unusual thresholds (outside [1e-6, 1e6])
+// boxes (non-finite coordinates, area outside [1e-30, 5e29]) or unusual thresholds (outside [1e-6, 1e6])
 // are re-evaluated with the reference formulation, division included (nms_iou_gt).  The fast and the
 // reference forms therefore agree on every input; tests/test_host.py checks the band logic on the CPU.
 struct IouThr {
@@ -32,12 +32,15 @@ static inline IouThr make_iou_thr(float thr) {
 
 // candidate flags
 static const int kFlagArea = 1;     // area passes TF's guard, i.e. !(area <= 0)
-static const int kFlagSpecial = 2;  // a coordinate is NaN or infinite: use the reference formulation
+static const int kFlagRegular = 2;  // finite coordinates and area in [1e-30, 5e29]: the band filter may decide pairs of
+                                    // such boxes (their union then lies in [1e-30, 1e30]); anything else is re-evaluated
+                                    // with the reference formulation
 
 __device__ __forceinline__ int box_flags(float4 b, const NBox &nb) {
   const bool finite = (fabsf(b.x) <= 3.402823466e+38f) && (fabsf(b.y) <= 3.402823466e+38f) &&
                       (fabsf(b.z) <= 3.402823466e+38f) && (fabsf(b.w) <= 3.402823466e+38f);
-  return (!(nb.area <= 0.0f) ? kFlagArea : 0) | (finite ? 0 : kFlagSpecial);
+  const bool regular = finite && (nb.area >= 1e-30f) && (nb.area <= 5e29f);
+  return (!(nb.area <= 0.0f) ? kFlagArea : 0) | (regular ? kFlagRegular : 0);
 }
 
 // Packed candidate: corner-normalised box + area + flags (LDS: one float4 and one float2 per candidate,
@@ -74,12 +77,12 @@ __device__ __forceinline__ NBox to_nbox(const PBox &p) {
 // nms_iou_gt" (the caller does that once per group of tests, which keeps the group free of branches so
 // that independent tests overlap).
 __device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, const IouThr &t, bool &irr) {
-  // finite coordinates: v_max/v_min equal std::max/std::min up to the sign of zero, which cannot change
-  // the outcome (it only reaches comparisons and products with exact zeros)
-  float ih = __builtin_fminf(i.ymax, j.ymax) - __builtin_fmaxf(i.ymin, j.ymin);
-  float iw = __builtin_fminf(i.xmax, j.xmax) - __builtin_fmaxf(i.xmin, j.xmin);
-  ih = __builtin_fmaxf(ih, 0.0f);
-  iw = __builtin_fmaxf(iw, 0.0f);
+  // finite coordinates (anything else lacks kFlagRegular and is re-evaluated): v_max/v_min equal std::max/std::min up
+  // to the sign of zero, which cannot change the outcome (it only reaches comparisons and products with exact zeros)
+  float ih = hw_min(i.ymax, j.ymax) - hw_max(i.ymin, j.ymin);
+  float iw = hw_min(i.xmax, j.xmax) - hw_max(i.xmin, j.xmin);
+  ih = hw_max(ih, 0.0f);
+  iw = hw_max(iw, 0.0f);
   const float inter = ih * iw;
   float uni = i.area + j.area;
   uni = uni - inter;
@@ -88,8 +91,10 @@ __device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, co
   const float lo = tt * 0.999999523162841796875f;  // 1 - 2^-21
   const bool yes = inter > hi;
   const bool no = inter < lo;
-  const bool area_ok = (i.flag & j.flag & kFlagArea) != 0;
-  const bool regular = (uni >= 1e-30f) & (uni <= 1e30f) & (((i.flag | j.flag) & kFlagSpecial) == 0);
+  // max(area_i, area_j) <= uni <= area_i + area_j: two regular boxes have a union in [1e-30, 1e30]
+  const int both = i.flag & j.flag;
+  const bool area_ok = (both & kFlagArea) != 0;
+  const bool regular = (both & kFlagRegular) != 0;
   // irregular or inside the band: exact re-evaluation needed (unless TF's area guard already says "no")
   irr = irr | (area_ok & !(regular & (yes | no)));
   return yes & area_ok;
