@@ -192,6 +192,10 @@ __device__ __forceinline__ float4 encode_box(float4 bx, float4 g) {
   return o;
 }
 
+// __ballot takes an int, which costs a v_cndmask + v_cmp to turn a lane mask that already sits in SGPRs into an int and
+// back; this form takes the predicate as it is.
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // ---- bare hardware max / min ------------------------------------------------------------------------
 // __builtin_fmaxf / fminf lower to llvm.maxnum / minnum, which in IEEE mode canonicalise both inputs first (a v_max_f32
 // x, x each): three instructions per max.  Where the caller has established that neither operand is NaN the bare

@@ -7,13 +7,15 @@
 //   1. sort_select orders the top-K candidates (score desc, index asc) -- sort_select.hip;
 //   2. `bm_prepare_kernel` decodes them once into packed boxes (corner-normalised box, area, flags);
 //   3. per PHASE (a band of kBandBlocks 64-candidate column blocks, i.e. 2048 candidates):
-//      `bm_tiles_kernel` (whole grid): 64x64 tiles of suppression words = ballot over the 64 column boxes of
-//         "IoU(row, col) > thr and row before col".  Rows are (a) the boxes KEPT in earlier bands, compacted (a box that
+//      `bm_tiles_kernel` (whole grid): 64x64 tiles of suppression words; lane = column box, and the lane's word
+//         collects over the tile's 64 rows the bits "IoU(row, col) > thr and row before col" (COLUMN words: no ballot, no
+//         cross-lane traffic in the tile; the scan only ever asks "is this column hit by one of these kept rows").  Rows are (a) the boxes KEPT in earlier bands, compacted (a box that
 //         was suppressed can suppress nobody, so only ~R of the cb0*64 earlier candidates are rows), and (b) the band's own
 //         candidates up to the column's block (undecided yet);
 //      `bm_scan_kernel` (one workgroup per image): ORs the (a) words into the band's `removed` words, then walks the
 //         band's blocks in order: wave 0 resolves the greedy order inside a block in parallel rounds from the block's
-//         transposed diagonal tile, all waves fold the kept rows' (b) words into the later blocks of the band.
+//         diagonal tile, then every wave marks in one later block of the band the columns hit by the block's kept rows
+//         (one AND and one ballot).
 //      An image that has its R boxes (or runs out of candidates) writes its outputs and marks itself done; later phases
 //      return at once for it, so the work is proportional to the candidates actually consumed, in bands of 2048.
 // All state between kernels lives in the caller's workspace; nothing synchronises with the host.
@@ -40,9 +42,9 @@ struct BitmaskParams {
   float4 *pbox;                 // (B, nb*64)
   float2 *paf;                  // (B, nb*64)   (area, flags as int bits)
   int Rx;                       // R_nms rounded up to 64: row capacity of xmask
-  unsigned long long *xmask;    // (B, nb, Rx)              xmask[cb][kept position]: rows = boxes kept in earlier bands
-  unsigned long long *mask;     // (B, nb, kBandBlocks*64)  mask[cb][row - first row of cb's band]: rows of the same band
-  unsigned long long *diag_t;   // (B, nb*64)  transposed diagonal tiles: bit r of diag_t[col] = "row r of col's block suppresses col"
+  // column words: element [cb][g*64 + lane] belongs to column box cb*64 + lane, bit r = "row r of row group g suppresses it"
+  unsigned long long *xmask;    // (B, nb, Rx)              row groups = the boxes kept in earlier bands, 64 at a time
+  unsigned long long *mask;     // (B, nb, kBandBlocks*64)  row groups = the blocks of cb's own band (group = rb - band start)
   unsigned long long *removed;  // (B, nb)
   int *state;                   // (B, 4): nk, done
   int *kidx;                    // (B, R_nms) sorted positions of the kept boxes
@@ -82,6 +84,38 @@ __global__ __launch_bounds__(256) void bm_prepare_kernel(BitmaskParams p) {
       p.state[b * 4 + 1] = 0;
     }
   }
+}
+
+// This lane's column box against the 64 rows of a tile: bit r of the result = "row r suppresses the column".  Fully
+// unrolled so that the bit positions are immediates (a select and an OR per test, on one half of the word).
+template <bool DIAG>
+__device__ __forceinline__ unsigned long long tile_column_word(const float4 *rows_box, const float2 *rows_af, const PBox &me,
+                                                               const IouThr &thr, int lane) {
+  unsigned lo = 0u, hi = 0u;
+#pragma unroll
+  for (int r0 = 0; r0 < 64; r0 += 4) {
+    PBox rbx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rbx[u] = load_pbox(rows_box, rows_af, r0 + u);
+    bool irr = false;
+    bool bit[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rbx[u], me, thr, irr);
+    if (__builtin_expect(__any(irr || thr.slow_only), 0)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rbx[u]), to_nbox(me), thr.thr);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = r0 + u;
+      const bool hit = DIAG ? (bit[u] && (r < lane)) : bit[u];
+      if (r < 32)
+        lo |= hit ? (1u << r) : 0u;
+      else
+        hi |= hit ? (1u << (r - 32)) : 0u;
+    }
+  }
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // grid (band column blocks, ceil((gx + band blocks) / 4), B), block 256: wave w <-> row group g = 4*blockIdx.y + w.
@@ -125,45 +159,16 @@ __global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0,
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // rows of earlier bands all precede the column; inside the band only rows before the column count
-  const int first_row = cross ? -64 : rb * 64;
-  unsigned long long mine = 0ull, mycol = 0ull;
-  for (int r0 = 0; r0 < 64; r0 += 4) {
-    PBox rbx[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) rbx[u] = load_pbox(s_box[w], s_af[w], r0 + u);
-    bool irr = false;
-    bool bit[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rbx[u], me, p.iou, irr);
-    if (__builtin_expect(__any(irr || p.iou.slow_only), 0)) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rbx[u]), to_nbox(me), p.iou.thr);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool hit = bit[u] && (first_row + r0 + u < jcol);
-      const unsigned long long word = __ballot(hit);
-      if (lane == r0 + u) mine = word;
-      mycol |= (unsigned long long)hit << (r0 + u);
-    }
-  }
-  if (cross) {
-    p.xmask[((long long)b * p.nb + cb) * p.Rx + g * 64 + lane] = mine;
-  } else {
-    p.mask[((long long)b * p.nb + cb) * (kBandBlocks * 64) + (rb - cb0) * 64 + lane] = mine;
-    if (rb == cb) p.diag_t[(long long)b * Kp + jcol] = mycol;  // the scan resolves a block from its columns
-  }
-}
-
-__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, off, 64);
-    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), off, 64);
-    v |= ((unsigned long long)hi << 32) | lo;
-  }
-  return v;
+  // rows of earlier bands and of earlier blocks all precede the column; inside the diagonal tile only rows before it count
+  unsigned long long word;
+  if (!cross && rb == cb)
+    word = tile_column_word<true>(s_box[w], s_af[w], me, p.iou, lane);
+  else
+    word = tile_column_word<false>(s_box[w], s_af[w], me, p.iou, lane);
+  if (cross)
+    p.xmask[((long long)b * p.nb + cb) * p.Rx + g * 64 + lane] = word;
+  else
+    p.mask[((long long)b * p.nb + cb) * (kBandBlocks * 64) + (rb - cb0) * 64 + lane] = word;
 }
 
 // One workgroup (1024 threads) per image.  LDS: removed[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
   const int b = blockIdx.x;
   if (p.state[b * 4 + 1]) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int nb = p.nb, Kp = nb * 64, R = p.R_nms;
+  const int nb = p.nb, R = p.R_nms;
   int cb1 = cb0 + kBandBlocks;
   if (cb1 > nb) cb1 = nb;
   constexpr int BW = kBandBlocks * 64;  // rows of a band
@@ -186,25 +191,29 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
   for (int i = tid; i < nk; i += 1024) kidx[i] = p.kidx[(long long)b * R + i];
   __syncthreads();
 
-  // (i) the boxes kept in earlier bands suppress into this band: one wave per column block ORs their words
+  // (i) the boxes kept in earlier bands suppress into this band: one wave per column block; a column is removed if any of
+  // its words over the kept rows is non-zero (row slots past nk hold boxes that overlap nobody)
   if (cb0 > 0 && nk > 0) {
     const unsigned long long *xm = p.xmask + (long long)b * nb * p.Rx;
     for (int cb = cb0 + w; cb < cb1; cb += 16) {
       unsigned long long acc = 0ull;
       const unsigned long long *col = xm + (long long)cb * p.Rx;
 #pragma unroll 4
-      for (int k0 = 0; k0 < nk; k0 += 64) acc |= col[k0 + lane];  // lanes past nk hold zero words (written by the tiles)
-      acc = wave_or64(acc);
-      if (lane == 0) removed[cb] |= acc;
+      for (int k0 = 0; k0 < nk; k0 += 64) acc |= col[k0 + lane];
+      const unsigned long long hitw = ballot64(acc != 0ull);
+      if (lane == 0) removed[cb] |= hitw;
     }
     __syncthreads();
   }
 
   // (ii) the band's blocks in order.  Nothing a block needs from memory depends on the blocks before it, so the loads run
-  // one block ahead of the serial chain: the band's transposed diagonal tiles sit in LDS, the words to fold after block
+  // one block ahead of the serial chain: the band's diagonal tiles sit in LDS, the words to fold after block
   // cb + 1 are requested while block cb is resolved.
   unsigned long long *s_diag = reinterpret_cast<unsigned long long *>(kidx + ((R + 1) & ~1));  // [kBandBlocks * 64]
-  for (int i = tid; i < (cb1 - cb0) * 64; i += 1024) s_diag[i] = p.diag_t[(long long)b * Kp + cb0 * 64 + i];
+  for (int i = tid; i < (cb1 - cb0) * 64; i += 1024) {  // diagonal tile of block cb0 + i/64: row group i/64 of its own column
+    const int blk = i >> 6;
+    s_diag[i] = mask[(long long)(cb0 + blk) * BW + blk * 64 + (i & 63)];
+  }
   unsigned long long f1n = 0ull, f2n = 0ull;
   if (cb0 + 1 + w < cb1) f1n = mask[(long long)(cb0 + 1 + w) * BW + lane];
   if (cb0 + 17 + w < cb1) f2n = mask[(long long)(cb0 + 17 + w) * BW + lane];
@@ -252,11 +261,15 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
     __syncthreads();
     const unsigned long long kb = s_kept;
     nk = s_nk;
-    // fold the kept rows' words into the later blocks of the band: LDS atomics (only lanes with something to add) instead
-    // of a 6-step cross-lane reduction, whose dependent ds_bpermute chain cost more than the resolve
-    const bool mine = (kb >> lane) & 1ull;
-    if (mine && f1 != 0ull) atomicOr(&removed[c1], f1);  // f1 / f2 are zero beyond the band
-    if (mine && f2 != 0ull) atomicOr(&removed[c2], f2);
+    // the columns of the later blocks that one of this block's kept rows suppresses: one AND and one ballot per block
+    if (c1 < cb1) {
+      const unsigned long long h1 = ballot64((f1 & kb) != 0ull);
+      if (lane == 0) removed[c1] |= h1;
+    }
+    if (c2 < cb1) {
+      const unsigned long long h2 = ballot64((f2 & kb) != 0ull);
+      if (lane == 0) removed[c2] |= h2;
+    }
     // kBandBlocks <= 32: c1 and c2 cover every later block of the band
     __syncthreads();
   }
@@ -298,7 +311,7 @@ struct BitmaskWorkspace {
   int *counts;
   float4 *pbox;
   float2 *paf;
-  unsigned long long *xmask, *mask, *diag_t, *removed;
+  unsigned long long *xmask, *mask, *removed;
   int *state, *kidx;
   size_t bytes;
 };
@@ -320,7 +333,6 @@ static BitmaskWorkspace carve_bitmask(void *ws, int B, int K, int R) {
   const size_t Rx = (size_t)((R > 0 ? R : 1) + 63) / 64 * 64;
   w.xmask = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * Rx * 8));
   w.mask = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * kBandBlocks * 64 * 8));
-  w.diag_t = reinterpret_cast<unsigned long long *>(take((size_t)B * Kp * 8));
   w.removed = reinterpret_cast<unsigned long long *>(take((size_t)B * nb * 8));
   w.state = reinterpret_cast<int *>(take((size_t)B * 16));
   w.kidx = reinterpret_cast<int *>(take((size_t)B * (R > 0 ? R : 1) * 4));
@@ -379,7 +391,6 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   p.Rx = (R_nms + 63) / 64 * 64;
   p.xmask = w.xmask;
   p.mask = w.mask;
-  p.diag_t = w.diag_t;
   p.removed = w.removed;
   p.state = w.state;
   p.kidx = w.kidx;

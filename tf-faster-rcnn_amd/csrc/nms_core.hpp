@@ -92,9 +92,10 @@ __device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, co
   const bool yes = inter > hi;
   const bool no = inter < lo;
   // max(area_i, area_j) <= uni <= area_i + area_j: two regular boxes have a union in [1e-30, 1e30]
+  // (a regular box always has the area flag too: the AND of two flag words is 0, kFlagArea or kFlagArea | kFlagRegular)
   const int both = i.flag & j.flag;
-  const bool area_ok = (both & kFlagArea) != 0;
-  const bool regular = (both & kFlagRegular) != 0;
+  const bool area_ok = both != 0;
+  const bool regular = both == (kFlagArea | kFlagRegular);
   // irregular or inside the band: exact re-evaluation needed (unless TF's area guard already says "no")
   irr = irr | (area_ok & !(regular & (yes | no)));
   return yes & area_ok;
@@ -212,7 +213,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
         d = d | dd;
         if (__all(d || (j >= nc))) break;
       }
-      const unsigned long long word = __ballot(d && (j < nc));
+      const unsigned long long word = ballot64(d && (j < nc));
       if (lane == 0 && word != 0ull) atomicOr(&L.dead[j >> 6], word);
     }
   }
@@ -251,7 +252,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const unsigned long long word = __ballot(bit[u] & (irow0 + u < jcol) & (jcol < nc));
+        const unsigned long long word = ballot64(bit[u] & (irow0 + u < jcol) & (jcol < nc));
         if (lane == 0) L.mask[(irow0 + u) * G + cg] = word;
       }
     }
