@@ -13,7 +13,10 @@ Measured alternatives (BASELINE config 2, MI355X; ablations with FRCNN_PIPE_SKIP
 per batch on one stream and 105 us when two streams alternate batches, but with the proposal and Decoder kernels present
 two crop lanes give no gain (136 us per batch either way: the single-workgroup kernels slow down under two overlapping
 crops and become the critical chain); confining them to reserved CUs with hipExtStreamCreateWithCUMask makes every
-cross-stream event wait cost ~200 us.  Hence one pooling stream.
+cross-stream event wait cost ~200 us; a persistent crop kernel of 1024-thread workgroups that owns a fixed number of CUs
+(so that the small kernels always find free ones and two crop launches can run side by side) is 10 % slower than the
+box-per-workgroup kernel on the whole chip and its two-lane form reached only 180 us per batch.  Hence one pooling stream
+and the plain kernel.
 
 Host cost per batch is three C-ABI calls and a handful of event operations: outputs live in a ring of
 ``depth`` preallocated slots, so nothing is allocated after the first batch of a given shape.
