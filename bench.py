@@ -117,6 +117,9 @@ def main() -> None:
                     help="pipeline: stages on three HIP streams, --depth batches in flight (tf_faster_rcnn_amd.pipeline); "
                          "sequential: the three layers one after the other on one stream")
     ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend for the barrier / max-over-ranks (nccl = RCCL)")
+    ap.add_argument("--device", type=int, default=None,
+                    help="GPU index for this rank (default LOCAL_RANK); lets a 1-GPU box rehearse the N-rank launch path")
     ap.add_argument("--no-other-schedule", action="store_true",
                     help="do not time the other schedule afterwards (profiling runs: one schedule per kernel trace)")
     args = ap.parse_args()
@@ -125,13 +128,17 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    dev_index = local_rank if args.device is None else args.device
     if world > 1:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(0 if args.device is None else args.device)
     device = torch.device("cuda", torch.cuda.current_device())
 
     import tf_faster_rcnn_amd as pkg
@@ -195,7 +202,7 @@ def main() -> None:
     elapsed = timed(step, True)
     host_ms = host_s[0] / max(args.steps, 1) * 1e3
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
