@@ -1,0 +1,147 @@
+"""GPU parity, randomised: many small random shapes / thresholds per entry point against the CPU oracle (bit for bit).
+
+The shapes are drawn from a fixed seed, so the suite is deterministic; it complements tests/test_gpu_parity.py (named
+configurations and edge cases) by sweeping the dispatch boundaries of the kernels: chunk and band sizes, vector / scalar
+paths, the schedules behind frcnn_roi_bbox, odd depths, K not a multiple of 64, R above and below K.
+"""
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+torch = pytest.importorskip("torch")
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_parity import assert_bits, dev  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import tf_faster_rcnn_amd as p
+    return p
+
+
+def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
+    rng = np.random.default_rng(2024)
+    for case in range(360):
+        G = int(rng.integers(3, 24))
+        N = G * G * 9
+        K = int(rng.integers(1, N + 1))
+        R = int(rng.integers(1, min(2 * K, 2500) + 1))
+        thr = float(rng.choice([0.1, 0.3, 0.5, 0.7, 0.9]))
+        B = int(rng.integers(1, 4))
+        schedule = ("fused", "bitmask", "unfused")[case % 3]
+        monkeypatch.delenv("FRCNN_ROI_BBOX_UNFUSED", raising=False)
+        monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
+        if schedule == "unfused":
+            monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+        hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+        hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
+        anchors = oracle.generate_anchors(hp)
+        deltas, scores = synth.rpn_outputs(1000 + case, B, G, unique_scores=bool(case % 4))
+        if case % 5 == 0:
+            deltas = (deltas * 0.1).astype(np.float32)  # heavy overlap: long suppression chains
+        got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+        want = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, thr)
+        assert_bits(got, want, f"RoIBBox fuzz case {case}: {schedule} B={B} G={G} K={K} R={R} thr={thr}")
+
+
+def test_fuzz_roi_pooling(pkg, monkeypatch):
+    rng = np.random.default_rng(7)
+    for case in range(240):
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 20)), int(rng.integers(1, 20))
+        C = int(rng.choice([1, 3, 4, 8, 20, 36, 64, 100, 576]))
+        R = int(rng.integers(1, 40))
+        ph, pw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        monkeypatch.setenv("FRCNN_CROP_SLICE", str(case % 2))
+        fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+        rois = rng.uniform(-0.2, 1.2, (B, R, 4)).astype(np.float32)  # inverted and out-of-image boxes included
+        hp = synth.hyper_params(pooling_size=(ph, pw))
+        got = pkg.faster_rcnn.RoIPooling(hp)([dev(fm), dev(rois)])
+        want = oracle.roi_pooling(fm, rois, (ph, pw))
+        assert_bits(got, want, f"RoIPooling fuzz case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw})")
+
+
+def test_fuzz_decoder(pkg, monkeypatch):
+    rng = np.random.default_rng(11)
+    for case in range(240):
+        B, R, L = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(2, 30))
+        T = int(rng.integers(1, 300))
+        thr = float(rng.choice([0.05, 0.3, 0.5, 0.8]))
+        monkeypatch.setenv("FRCNN_DECODER_UNFUSED", str(case % 2))
+        hp = synth.hyper_params()
+        rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+        deltas = rng.normal(0, 0.5, (B, R, L * 4)).astype(np.float32)
+        if case % 3 == 0:
+            probs = rng.random((B, R, L)).astype(np.float32)  # un-normalised: many classes fire per RoI
+        else:
+            logits = rng.normal(0, 1, (B, R, L)) + 5 * np.eye(L)[rng.integers(0, L, (B, R))]
+            probs = (np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)).astype(np.float32)
+        layer = pkg.faster_rcnn.Decoder(hp["variances"], L, max_total_size=T, score_threshold=thr)
+        got = layer([dev(rois), dev(deltas), dev(probs)])
+        want = oracle.decoder(rois, deltas, probs, hp["variances"], L, T, thr)
+        for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
+            assert_bits(g, w, f"Decoder fuzz case {case}: B={B} R={R} L={L} T={T} thr={thr} {name}")
+
+
+def test_fuzz_iou_and_targets(pkg):
+    rng = np.random.default_rng(13)
+    for case in range(160):
+        B, G, M = int(rng.integers(1, 5)), int(rng.integers(2, 20)), int(rng.integers(1, 40))
+        hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+        hp.update(feature_map_shape=G, total_pos_bboxes=int(rng.integers(0, 40)), total_neg_bboxes=int(rng.integers(0, 40)))
+        anchors = oracle.generate_anchors(hp)
+        N = anchors.shape[0]
+        gt, labels = synth.gt_boxes(300 + case, B, M)
+        assert_bits(pkg.bbox_utils.generate_iou_map(dev(anchors), dev(gt)), oracle.generate_iou_map(anchors, gt),
+                    f"iou map fuzz case {case}: B={B} G={G} M={M}")
+        rp = rng.integers(1, 500, (B, N), dtype=np.int32)
+        rn = rng.integers(1, 500, (B, N), dtype=np.int32)
+        got_d, got_l = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp,
+                                                                    random_masks=(dev(rp), dev(rn)))
+        want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
+        assert_bits(got_l, want_l, f"rpn labels fuzz case {case}")
+        assert_bits(got_d, want_d, f"rpn deltas fuzz case {case}")
+        # RoIDelta on jittered gts + random boxes
+        R, L = int(rng.integers(1, 300)), int(rng.integers(2, 25))
+        rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+        k = min(R, M)
+        rois[:, :k] = np.clip(gt[:, :k] + rng.normal(0, 0.03, (B, k, 4)), 0, 1)
+        lab = np.where(labels >= 0, labels % (L - 1 if L > 2 else 1) + (1 if L > 2 else 0), labels).astype(np.int32)
+        hp_r = dict(hp, total_labels=L)
+        rp2 = rng.integers(1, 500, (B, R), dtype=np.int32)
+        rn2 = rng.integers(1, 500, (B, R), dtype=np.int32)
+        gd, gl = pkg.faster_rcnn.RoIDelta(hp_r)([dev(rois), dev(gt), dev(lab)], random_masks=(dev(rp2), dev(rn2)))
+        wd, wl = oracle.roi_delta(rois, gt, lab, hp_r, (rp2, rn2))
+        assert_bits(gl, wl, f"RoIDelta labels fuzz case {case}")
+        assert_bits(gd, wd, f"RoIDelta deltas fuzz case {case}")
+
+
+def test_fuzz_top_k_and_combined_nms(pkg):
+    rng = np.random.default_rng(17)
+    for case in range(160):
+        B, N = int(rng.integers(1, 4)), int(rng.integers(1, 5000))
+        K = int(rng.integers(1, N + 1))
+        scores = rng.random((B, N)).astype(np.float32)
+        if case % 3 == 0:
+            scores = np.round(scores * 50) / 50  # many ties
+        gv, gi = pkg.bbox_utils.top_k(dev(scores), K)
+        wv, wi = oracle.top_k(scores, K)
+        assert_bits(gi, wi, f"top_k fuzz case {case} indices (N={N}, K={K})")
+        assert_bits(gv, wv, f"top_k fuzz case {case} values")
+        n, c = int(rng.integers(1, 300)), int(rng.integers(1, 8))
+        q = c if case % 2 else 1
+        boxes = rng.uniform(-0.1, 1.1, (B, n, q, 4)).astype(np.float32)
+        sc = rng.random((B, n, c)).astype(np.float32)
+        mpc, mt = int(rng.integers(1, 120)), int(rng.integers(1, 200))
+        kw = dict(max_output_size_per_class=mpc, max_total_size=mt, iou_threshold=float(rng.choice([0.2, 0.5, 0.8])),
+                  score_threshold=float(rng.choice([-np.inf, 0.3, 0.6])))
+        got = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(sc), **kw)
+        want = oracle.combined_non_max_suppression(boxes, sc, kw["max_output_size_per_class"], kw["max_total_size"],
+                                                   kw["iou_threshold"], kw["score_threshold"])
+        for g, w, name in zip(got, want, ("boxes", "scores", "classes", "valid")):
+            assert_bits(g, w, f"combined NMS fuzz case {case} {name} (n={n}, q={q}, c={c})")
