@@ -79,16 +79,19 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     return decode_box(rois[r], scale_deltas(deltas[(long long)r * L + cls], p.v0, p.v1, p.v2, p.v3));
   };
 
+  FRCNN_STAMP(20);
   for (int i = tid; i < 3 * (kDecMaxClasses + 4); i += kNT) ccount[i] = 0;  // ccount, cstart, kcount are contiguous
+  // The image's class probabilities are staged once, coalesced, in the (not yet used) sort buffer: phase A reads every row
+  // twice, and a lane walking its own 84-byte row straight from memory pays two uncoalesced round trips.
+  float *sprob = reinterpret_cast<float *>(perm);  // [R*L] <= 4*Vcap bytes
+  for (int i = tid; i < R * L; i += kNT) sprob[i] = probs[i];
   __syncthreads();
 
   // ---- A. candidates, compacted in (roi, class) order -------------------------------------------------
-  const int E = (R + kNT - 1) / kNT;
-  const int r0 = tid * E;
-  const int r1 = (r0 + E < R) ? (r0 + E) : R;
-  int cnt = 0;
-  for (int r = r0; r < r1; ++r) {
-    const float *row = probs + (long long)r * L;
+  // A1: one lane per RoI: is its first-max argmax a foreground class?  (flags parked in the kept-list buffer, free until C)
+  uint16_t *roi_fg = klist;  // [R] <= Vcap
+  for (int r = tid; r < R; r += kNT) {
+    const float *row = sprob + r * L;
     float best = -3.402823466e+38f;  // [TF-recall] tf.argmax: first maximal index (strict '>' from lowest())
     int am = 0;
     for (int l = 0; l < L; ++l) {
@@ -98,52 +101,78 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
         am = l;
       }
     }
-    if (am != 0)
-      for (int l = 0; l < L; ++l) cnt += (row[l] > p.score_thr);
+    roi_fg[r] = (uint16_t)(am != 0);
+  }
+  __syncthreads();
+  FRCNN_STAMP(21);
+  // A2: the R*L (roi, class) elements in flat order, a contiguous run per thread: count, scan, place
+  const int RL = R * L;
+  const int E = (RL + kNT - 1) / kNT;
+  const int e0 = tid * E;
+  const int e1 = (e0 + E < RL) ? (e0 + E) : RL;
+  int cnt = 0;
+  {
+    int r = (e0 < RL) ? e0 / L : 0;
+    int l = e0 - r * L;
+    for (int e = e0; e < e1; ++e) {
+      cnt += (roi_fg[r] != 0) && (sprob[e] > p.score_thr);
+      if (++l == L) {
+        l = 0;
+        ++r;
+      }
+    }
   }
   int V;
   int pos = block_excl_scan(cnt, wsum, V);
-  for (int r = r0; r < r1; ++r) {
-    const float *row = probs + (long long)r * L;
-    float best = -3.402823466e+38f;
-    int am = 0;
-    for (int l = 0; l < L; ++l) {
-      const float v = row[l];
-      if (v > best) {
-        best = v;
-        am = l;
+  if (cnt) {
+    int r = e0 / L;
+    int l = e0 - r * L;
+    for (int e = e0; e < e1; ++e) {
+      const float v = sprob[e];
+      if (roi_fg[r] != 0 && v > p.score_thr && pos < Vcap) {
+        key[pos] = ~f_order_key(v);
+        pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
+        atomicAdd(&ccount[l], 1);
+        ++pos;
       }
-    }
-    if (am != 0) {
-      for (int l = 0; l < L; ++l) {
-        const float v = row[l];
-        if (v > p.score_thr && pos < Vcap) {
-          key[pos] = ~f_order_key(v);
-          pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
-          perm[pos] = (uint16_t)pos;
-          atomicAdd(&ccount[l], 1);
-          ++pos;
-        }
+      if (++l == L) {
+        l = 0;
+        ++r;
       }
     }
   }
   if (V > Vcap) V = Vcap;  // cannot happen: Vcap >= R*L
   __syncthreads();
+  FRCNN_STAMP(22);
 
   // ---- B. order by (class asc, score desc, roi asc) -----------------------------------------------------
   int soff = 0;  // offset of the sorted order inside perm
   if (V <= kNT) {
-    uint64_t mine = 0;
-    if (tid < V) mine = ((uint64_t)(pk[tid] >> 24) << 32) | key[tid];
-    int rank = 0;
-    for (int j = 0; j < V; ++j) {  // LDS broadcast reads
-      const uint64_t other = ((uint64_t)(pk[j] >> 24) << 32) | key[j];
-      rank += (other < mine) || (other == mine && j < tid);
+    // rank by counting, all 1024 threads: `parts` threads share one candidate, each scanning a slice of the others
+    // (LDS broadcast reads), partial ranks summed in LDS.  V is a few hundred: one thread per candidate left 3/4 of the
+    // workgroup idle for V dependent LDS round trips.
+    const int Vp = (V + 63) & ~63;
+    const int parts = Vp > 0 ? kNT / Vp : 1;  // >= 1
+    uint32_t *racc = hist;                     // [V] partial-rank accumulators
+    for (int i = tid; i < V; i += kNT) racc[i] = 0u;
+    __syncthreads();
+    const int part = Vp > 0 ? tid / Vp : 0;
+    const int elem = tid - part * Vp;
+    if (part < parts && elem < V) {
+      const uint64_t mine = ((uint64_t)(pk[elem] >> 24) << 32) | key[elem];
+      const int j0 = (int)((long long)V * part / parts), j1 = (int)((long long)V * (part + 1) / parts);
+      int rank = 0;
+      for (int j = j0; j < j1; ++j) {
+        const uint64_t other = ((uint64_t)(pk[j] >> 24) << 32) | key[j];
+        rank += (other < mine) || (other == mine && j < elem);
+      }
+      atomicAdd(&racc[elem], (uint32_t)rank);
     }
     __syncthreads();
-    if (tid < V) perm[rank] = (uint16_t)tid;
+    if (tid < V) perm[racc[tid]] = (uint16_t)tid;
     __syncthreads();
   } else {
+    for (int i = tid; i < V; i += kNT) perm[i] = (uint16_t)i;  // (published by the sort's first barrier)
     soff = block_sort_digits(
         [&](int slot, int pass) -> uint32_t { return pass < 4 ? (key[slot] >> (8 * pass)) : (pk[slot] >> 24); }, 5, perm,
         Vcap, V, hist, wsum);
@@ -167,6 +196,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
   }
   __syncthreads();
 
+  FRCNN_STAMP(23);
   // ---- C. per-class greedy NMS, one wave per class segment ------------------------------------------------
   if (w < nms_waves) {
     float4 *cbox = reinterpret_cast<float4 *>(wave_area + (size_t)w * dec_wave_bytes(Rpc4));
@@ -286,6 +316,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
   }
   __syncthreads();
 
+  FRCNN_STAMP(24);
   // ---- D. cross-class merge: rank of every kept entry, output ------------------------------------------------
   // koff (exclusive prefix of kcount) reuses ccount; wave 0 scans.
   int *koff = ccount;
@@ -306,41 +337,72 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     if (lane == 63) misc[0] = inc;
   }
   __syncthreads();
+  FRCNN_STAMP(26);
   const int total = misc[0];
   const int nvalid = total < T ? total : T;
-  for (int e = tid; e < total; e += kNT) {
-    int cls;
-    {
-      int lo = 0, hi = L - 1;  // last class with koff[cls] <= e
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (koff[mid] <= e) lo = mid; else hi = mid - 1;
-      }
-      cls = lo;
+  // The rank of a kept entry = its position in its own class + the number of entries of every other class that precede it
+  // (binary searches: kept lists are ascending in key = descending score).  One work item per (entry, other class), spread
+  // over the whole workgroup, partial ranks summed in LDS (hist and perm are free by now); per-entry loops when the entries
+  // do not fit those arrays.
+  uint32_t *rank_acc = hist;   // [total]
+  uint16_t *ecls = perm;       // [total] class of entry e
+  const bool spread = total <= kNW * 256;
+  auto class_of = [&](int e) -> int {
+    int lo = 0, hi = L - 1;  // last class with koff[cls] <= e
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (koff[mid] <= e) lo = mid; else hi = mid - 1;
     }
+    return lo;
+  };
+  auto preceding = [&](int cls, uint32_t mykey, int c2) -> int {  // entries of class c2 before (mykey, cls)
+    const int n2 = kcount[c2];
+    const uint16_t *l2 = klist + cstart[c2];
+    int lo = 0, hi = n2;
+    if (c2 < cls) {  // equal keys: the lower class goes first
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key[l2[mid]] <= mykey) lo = mid + 1; else hi = mid;
+      }
+    } else {
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (key[l2[mid]] < mykey) lo = mid + 1; else hi = mid;
+      }
+    }
+    return lo;
+  };
+  if (spread) {
+    for (int e = tid; e < total; e += kNT) {
+      const int cls = class_of(e);
+      ecls[e] = (uint16_t)cls;
+      rank_acc[e] = (uint32_t)(e - koff[cls]);
+    }
+    __syncthreads();
+    const long long items = (long long)total * L;
+    for (long long it = tid; it < items; it += kNT) {
+      const int e = (int)(it / L);
+      const int c2 = (int)(it - (long long)e * L);
+      const int cls = (int)ecls[e];
+      if (c2 == cls || kcount[c2] == 0) continue;
+      const int slot = (int)klist[cstart[cls] + (e - koff[cls])];
+      const int before = preceding(cls, key[slot], c2);
+      if (before) atomicAdd(&rank_acc[e], (uint32_t)before);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < total; e += kNT) {
+    const int cls = spread ? (int)ecls[e] : class_of(e);
     const int kpos = e - koff[cls];
     const int slot = (int)klist[cstart[cls] + kpos];
-    const uint32_t mykey = key[slot];
-    int rank = kpos;
-    for (int c2 = 0; c2 < L; ++c2) {
-      const int n2 = kcount[c2];
-      if (c2 == cls || n2 == 0) continue;
-      const uint16_t *l2 = klist + cstart[c2];
-      // kept lists are ascending in key (= descending score).  Entries of class c2 that precede (mykey, cls):
-      // key2 < mykey, or key2 == mykey and c2 < cls.
-      int lo = 0, hi = n2;
-      if (c2 < cls) {
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (key[l2[mid]] <= mykey) lo = mid + 1; else hi = mid;
-        }
-      } else {
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (key[l2[mid]] < mykey) lo = mid + 1; else hi = mid;
-        }
-      }
-      rank += lo;
+    int rank;
+    if (spread) {
+      rank = (int)rank_acc[e];
+    } else {
+      const uint32_t mykey = key[slot];
+      rank = kpos;
+      for (int c2 = 0; c2 < L; ++c2)
+        if (c2 != cls && kcount[c2] != 0) rank += preceding(cls, mykey, c2);
     }
     if (rank < T) {
       const int r = (int)(pk[slot] & 0xFFFFFFu);
@@ -360,6 +422,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     if (p.out_labels) p.out_labels[(long long)b * T + r] = 0.0f;
   }
   if (tid == 0 && p.out_valid) p.out_valid[b] = nvalid;
+  FRCNN_STAMP(25);
 }
 
 // *handled stays false when the fused kernel cannot hold the problem in LDS; the caller then takes the

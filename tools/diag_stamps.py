@@ -57,3 +57,19 @@ tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
 print("---- beside 4 crop launches on another stream ----")
 for i in range(n):
     print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
+
+
+# ---- Decoder kernel phases (tags 20..26: start, argmax/count, compaction, order, per-class NMS, prefix, merge+write) ----
+hd, hpb = synth.head_outputs(0, 16, 300, 21)
+dec = pkg.faster_rcnn.Decoder(hp["variances"], 21)
+hd, hpb = torch.as_tensor(hd).cuda(), torch.as_tensor(hpb).cuda()
+for it in range(3):
+    torch.cuda.synchronize()
+    lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    dec([rois, hd, hpb])
+    torch.cuda.synchronize()
+n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+print("---- decoder kernel ----")
+for i in range(n):
+    print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
