@@ -57,7 +57,7 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool vali
 // Radix select over n elements.  keyf(i, key) -> bool valid (key: smaller = earlier).  Finds the key T
 // that the element of 1-based ascending rank `need` carries, and need_eq = how many elements equal to T
 // are inside the first `need` (to be taken in index order).  all = true when fewer than `need` valid
-// elements exist (then every valid element is inside).  hist: >= 256 uint32 of LDS, misc: >= 4 ints.
+// elements exist (then every valid element is inside).  hist: kNW*256 uint32 of LDS, misc: >= 4 ints.
 template <class KeyF>
 __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_t *hist, int *misc, uint32_t &T,
                                              int &need_eq, bool &all) {
@@ -68,14 +68,31 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
   all = false;
   for (int pass = 3; pass >= 0; --pass) {
     const int shift = pass * 8;
-    if (tid < 256) hist[tid] = 0;
+    // wave-private histograms (no cross-wave contention on the LDS atomics), summed below
+    for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
     __syncthreads();
-    const int n_up = (n + kNT - 1) / kNT * kNT;
-    for (int i = tid; i < n_up; i += kNT) {  // uniform trip count: hist_add uses wave ballots
-      uint32_t k = 0;
-      bool v = (i < n) && keyf(i, k);
-      v = v && (pass == 3 || (k >> (shift + 8)) == prefix);
-      hist_add(hist, (k >> shift) & 255u, v);
+    uint32_t *myhist = hist + w * 256;
+    if (pass == 3) {
+      // top digit of fp32 keys: a wave sees one or two distinct bins -> aggregate (uniform trip count for the ballots)
+      const int n_up = (n + kNT - 1) / kNT * kNT;
+      for (int i = tid; i < n_up; i += kNT) {
+        uint32_t k = 0;
+        const bool v = (i < n) && keyf(i, k);
+        hist_add(myhist, (k >> shift) & 255u, v);
+      }
+    } else {
+      // lower digits are spread over the 256 bins (and only keys with the right prefix count): plain LDS adds
+      for (int i = tid; i < n; i += kNT) {
+        uint32_t k = 0;
+        if (keyf(i, k) && (k >> (shift + 8)) == prefix) atomicAdd(&myhist[(k >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int ww = 0; ww < kNW; ++ww) sum += hist[ww * 256 + tid];
+      hist[tid] = sum;  // (row 0, column tid: read above by this thread only)
     }
     __syncthreads();
     if (w == 0) {
