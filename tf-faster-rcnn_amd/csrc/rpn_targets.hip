@@ -13,7 +13,7 @@
 // One 1024-thread workgroup per image; the per-anchor inputs (max IoU, random ints) are re-read from
 // global memory in each radix pass (36 KB per image, L2 resident) instead of being held in LDS, which
 // only keeps three N-bit maps.  Latency bound: ~0.3 MB of traffic per image.
-#include "common.hpp"
+#include "block_primitives.hpp"
 
 namespace frcnn {
 
@@ -39,16 +39,23 @@ __device__ __forceinline__ int draw_int(uint64_t seed, uint32_t stream, int b, i
 
 // Workgroup-cooperative selection.  keyf(n) -> int key (= mask * random); emit(n, in) is called once
 // for every n < N with in == (rank of n in the descending key order, ties by index) < S.
-// hist: 256 uint32 in LDS; misc: 8 ints in LDS; wsum: kTNW ints in LDS.
+// hist: 256 uint32 in LDS; misc: 8 ints in LDS; wsum: kTNW ints in LDS; kcache: N uint32 of LDS or NULL -- with it
+// keyf is evaluated once per element (its inputs usually sit in global memory) and the passes read LDS.
 template <class KeyF, class EmitF>
 __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t *hist, int *misc, int *wsum,
-                                               EmitF emit) {
+                                               EmitF emit, uint32_t *kcache = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (S <= 0 || S >= N) {  // uniform: nobody / everybody has rank < S
     const bool in = (S >= N) && (S > 0);
     for (int n = tid; n < N; n += kTNT) emit(n, in);
     return;
   }
+  if (kcache) {
+    __syncthreads();  // the cache may still be read by a previous selection
+    for (int n = tid; n < N; n += kTNT) kcache[n] = inv_key(keyf(n));
+    __syncthreads();
+  }
+  auto key_at = [&](int n) -> uint32_t { return kcache ? kcache[n] : inv_key(keyf(n)); };
   uint32_t prefix = 0;
   int need = S;
   for (int pass = 3; pass >= 0; --pass) {
@@ -56,9 +63,16 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
     __syncthreads();
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int n = tid; n < N; n += kTNT) {
-      const uint32_t k = inv_key(keyf(n));
-      if (pass == 3 || (k >> (shift + 8)) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+    {
+      // Keys are mask * (small random integer): the masked-out elements (key 0, usually most of the row) share every digit
+      // and the rest share the upper ones, so in every pass most lanes of a wave hit one or two bins -- wave-aggregated adds
+      // (hist_add) instead of thousands of serialised same-address LDS atomics.  Uniform trip count for its ballots.
+      const int n_up = (N + kTNT - 1) / kTNT * kTNT;
+      for (int n = tid; n < n_up; n += kTNT) {
+        const uint32_t k = (n < N) ? key_at(n) : 0u;
+        const bool v = (n < N) && (pass == 3 || (k >> (shift + 8)) == prefix);
+        hist_add(hist, (k >> shift) & 255u, v);
+      }
     }
     __syncthreads();
     if (w == 0) {
@@ -96,30 +110,20 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
   }
   const uint32_t T = prefix;
   const int need_eq = need;
-  // ordered pass: index-ordered rank among the elements with key == T
-  int eq_before = 0;
-  for (int base = 0; base < N; base += kTNT) {
-    const int n = base + tid;
-    uint32_t k = 0xFFFFFFFFu;
-    bool live = n < N;
-    if (live) k = inv_key(keyf(n));
-    const bool eq = live && (k == T);
-    const unsigned long long bal = __ballot(eq);
-    __syncthreads();
-    if (lane == 0) wsum[w] = __popcll(bal);
-    __syncthreads();
-    int wbase = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < kTNW; ++i) {
-      const int s = wsum[i];
-      if (i < w) wbase += s;
-      tot += s;
-    }
-    if (live) {
-      const int eq_rank = eq_before + wbase + __popcll(bal & lanemask_lt());
-      emit(n, (k < T) || (eq && eq_rank < need_eq));
-    }
-    eq_before += tot;
+  // index-ordered rank among the elements with key == T: every thread owns a contiguous run of elements, one block scan
+  // of the per-run counts gives the rank of its first equal element
+  const int E = (N + kTNT - 1) / kTNT;
+  const int n0 = tid * E;
+  const int n1 = (n0 + E < N) ? (n0 + E) : N;
+  int eq = 0;
+  for (int n = n0; n < n1; ++n) eq += (key_at(n) == T);
+  int total_eq;
+  int rank = block_excl_scan(eq, wsum, total_eq);
+  for (int n = n0; n < n1; ++n) {
+    const uint32_t k = key_at(n);
+    const bool is_eq = (k == T);
+    emit(n, (k < T) || (is_eq && rank < need_eq));
+    rank += is_eq;
   }
 }
 
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
     const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int N, int M,
     int total_pos, int total_neg, float v0, float v1, float v2, float v3, const float *__restrict__ max_iou,
     const int *__restrict__ argmax_row, const int *__restrict__ argmax_col, float *__restrict__ out_deltas,
-    float *__restrict__ out_labels) {
+    float *__restrict__ out_labels, int cache_keys) {
   extern __shared__ __attribute__((aligned(16))) uint32_t maps[];
   __shared__ uint32_t hist[256];
   __shared__ int misc[8];
@@ -157,10 +161,12 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   uint32_t *forced = maps;
   uint32_t *pos_sel = maps + words;
   uint32_t *neg_sel = maps + 2 * words;
+  uint32_t *kcache = cache_keys ? maps + 3 * words : nullptr;  // [N]
   const float *miou = max_iou + (long long)b * N;
   const int *rp = rnd_pos ? rnd_pos + (long long)b * N : nullptr;
   const int *rn = rnd_neg ? rnd_neg + (long long)b * N : nullptr;
 
+  FRCNN_STAMP(30);
   for (int i = tid; i < 3 * words; i += kTNT) maps[i] = 0u;
   if (tid == 0) s_pos_count = 0;
   __syncthreads();
@@ -173,6 +179,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   }
   __syncthreads();
 
+  FRCNN_STAMP(31);
   // :180,:188-189 positives, sub-sampled to total_pos
   auto pos_key = [&](int n) -> int {
     const bool msk = (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u);
@@ -185,8 +192,9 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
       atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
       atomicAdd(&s_pos_count, 1);
     }
-  });
+  }, kcache);
   __syncthreads();
+  FRCNN_STAMP(32);
   // :190-191
   const int neg_count = (total_pos + total_neg) - s_pos_count;
 
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   });
   __syncthreads();
 
+  FRCNN_STAMP(33);
   // :195-200 labels and regression targets
   for (int n = tid; n < N; n += kTNT) {
     const bool pos = (pos_sel[n >> 5] >> (n & 31)) & 1u;
@@ -222,10 +231,11 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
     d.w = d.w / v3;
     *reinterpret_cast<float4 *>(out_deltas + ((long long)b * N + n) * 4) = d;
   }
+  FRCNN_STAMP(34);
 }
 
 // models/faster_rcnn.py:218-234 (RoIDelta.call after the IoU reductions), one image per workgroup.
-// LDS: two R-bit maps, then the per-RoI encoded delta (float4) and label (int).
+// LDS: two R-bit maps, then the per-RoI encoded delta (float4), label (int) and selection key (uint32).
 __global__ __launch_bounds__(1024) void roi_delta_kernel(
     const float *__restrict__ rois, const float *__restrict__ gt_boxes, const int *__restrict__ gt_labels,
     const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int R, int M, int L,
@@ -242,6 +252,7 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
   uint32_t *neg_sel = maps + words;
   float4 *s_delta = reinterpret_cast<float4 *>(maps + words4);  // [R]
   int *s_label = reinterpret_cast<int *>(s_delta + R);           // [R]
+  uint32_t *kcache = reinterpret_cast<uint32_t *>(s_label + R);  // [R] selection keys
   const float *miou = max_iou + (long long)b * R;
   const int *rp = rnd_pos ? rnd_pos + (long long)b * R : nullptr;
   const int *rn = rnd_neg ? rnd_neg + (long long)b * R : nullptr;
@@ -257,7 +268,8 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
       R, total_pos, hist, misc, wsum,
       [&](int n, bool in) {
         if ((miou[n] > 0.5f) && in) atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
-      });
+      },
+      kcache);
   // :220-221 negatives: 0.1 < max IoU < 0.5, sub-sampled to total_neg
   select_largest(
       [&](int n) -> int {
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
       R, total_neg, hist, misc, wsum,
       [&](int n, bool in) {
         if ((miou[n] < 0.5f) && (miou[n] > 0.1f) && in) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
-      });
+      },
+      kcache);
   __syncthreads();
 
   // :222-230 per RoI: gathered gt box / label, encoded delta / variances
@@ -376,7 +389,9 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
   int rc = frcnn_iou_map_reduce(anchors, 0, gt_boxes, B, N, M, max_iou, argmax_row, argmax_col, keys, keys_bytes, stream);
   if (rc) return rc;
   const int words = (N + 31) >> 5;
-  const size_t lds = (size_t)3 * words * 4;
+  size_t lds = (size_t)3 * words * 4;
+  const int cache_keys = (lds + (size_t)N * 4 <= 128 * 1024) ? 1 : 0;  // the selections' keys, once instead of per pass
+  if (cache_keys) lds += (size_t)N * 4;
   auto kern = rpn_targets_kernel;
   if (lds > 48 * 1024) {
     rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
@@ -385,7 +400,7 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTNT), lds, (hipStream_t)stream, anchors, gt_boxes, gt_labels, rnd_pos,
                      rnd_neg, (unsigned long long)seed, N, M, total_pos, total_neg, variances[0], variances[1],
-                     variances[2], variances[3], max_iou, argmax_row, argmax_col, out_deltas, out_labels);
+                     variances[2], variances[3], max_iou, argmax_row, argmax_col, out_deltas, out_labels, cache_keys);
   return check_launch("rpn_targets");
 }
 
@@ -418,7 +433,7 @@ int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_
   int rc = frcnn_iou_map_reduce(rois, 1, gt_boxes, B, R, M, max_iou, argmax_row, nullptr, nullptr, 0, stream);
   if (rc) return rc;
   const int words = (R + 31) >> 5;
-  const size_t lds = (size_t)((2 * words + 3) & ~3) * 4 + (size_t)R * 20;
+  const size_t lds = (size_t)((2 * words + 3) & ~3) * 4 + (size_t)R * 24;
   auto kern = roi_delta_kernel;
   if (lds > 48 * 1024) {
     rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),

@@ -73,3 +73,20 @@ tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
 print("---- decoder kernel ----")
 for i in range(n):
     print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
+
+
+# ---- rpn_targets_kernel phases (tags 30..34: start, forced map, positive selection, negative selection, outputs) ----
+hp4 = pkg.train_utils.get_hyper_params("mobilenet_v2")
+gt, lab = synth.gt_boxes(0, 8, 100)
+rp_, rn_ = synth.sampling_ints(0, 8, anchors.shape[0])
+args4 = [torch.as_tensor(a).cuda() for a in (gt, lab, rp_, rn_)]
+for it in range(3):
+    torch.cuda.synchronize()
+    lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    pkg.train_utils.calculate_rpn_actual_outputs(anchors, args4[0], args4[1], hp4, random_masks=(args4[2], args4[3]))
+    torch.cuda.synchronize()
+n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+print("---- rpn_targets kernel ----")
+for i in range(n):
+    print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
