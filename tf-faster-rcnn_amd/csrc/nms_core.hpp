@@ -104,7 +104,7 @@ __device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, co
 // LDS layout for chunks of CH candidates (CH = 64 * G).
 template <int CH>
 struct NmsLds {
-  unsigned long long *mask;  // [CH * G] intra-chunk suppression words, mask[row * G + column group]
+  unsigned long long *mask;  // [CH * G] intra-chunk column words, mask[column * G + row group]
   unsigned long long *dead;  // [4]
   float4 *c_box;             // [CH] chunk boxes (corner-normalised)
   float2 *c_af;              // [CH] (area, flags)
@@ -184,6 +184,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
     const unsigned long long badw = __ballot(bad);  // candidates that fail the score threshold start dead
     if (lane == 0) L.dead[w] = badw;
   }
+  for (int i = tid; i < CH * G; i += NT) L.mask[i] = 0ull;  // column words, OR-ed together in phase b
   __syncthreads();
   FRCNN_STAMP(10);
 
@@ -216,10 +217,14 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       const unsigned long long word = ballot64(d && (j < nc));
       if (lane == 0 && word != 0ull) atomicOr(&L.dead[j >> 6], word);
     }
+    __syncthreads();  // phase b skips the rows that are dead by now
   }
   FRCNN_STAMP(11);
 
-  // ---- b. intra-chunk IoU tiles (upper triangle), ROWS rows per work item, four rows per step ----
+  // ---- b. intra-chunk IoU tiles (upper triangle) as COLUMN words ----------------------------------
+  // lane = column candidate; mask[col * G + rg] collects over the rows of row group rg the bits "row suppresses col and
+  // comes before it".  A work item is ROWS rows of one tile; rows already dead are skipped four at a time (a suppressed
+  // candidate suppresses nobody), partial words are OR-ed in LDS.
   for (int item = w; item < TILES * SPLIT; item += NWV) {
     const int tile = item / SPLIT;
     const int part = item - tile * SPLIT;
@@ -236,9 +241,13 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
     if (rg * 64 >= nc || cg * 64 >= nc) continue;  // wave-uniform
     const int jcol = cg * 64 + lane;
     const PBox me = load_pbox(L.c_box, L.c_af, jcol);
+    const unsigned long long alive_rows = uniform64(~L.dead[rg]);
     static_assert(ROWS % 4 == 0, "rows per item must be a multiple of 4");
+    unsigned long long bits = 0ull;
     for (int i0 = 0; i0 < ROWS; i0 += 4) {
-      const int irow0 = rg * 64 + part * ROWS + i0;
+      const int rl0 = part * ROWS + i0;  // row offset inside the group
+      if (((alive_rows >> rl0) & 0xFull) == 0ull) continue;  // wave-uniform
+      const int irow0 = rg * 64 + rl0;
       PBox rb[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) rb[u] = load_pbox(L.c_box, L.c_af, irow0 + u);
@@ -252,76 +261,65 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const unsigned long long word = ballot64(bit[u] & (irow0 + u < jcol) & (jcol < nc));
-        if (lane == 0) L.mask[(irow0 + u) * G + cg] = word;
+        const bool hit = bit[u] & (irow0 + u < jcol) & (jcol < nc);
+        bits |= (unsigned long long)hit << (rl0 + u);
       }
     }
+    if (bits != 0ull) atomicOr(&L.mask[jcol * G + rg], bits);
   }
   __syncthreads();
   FRCNN_STAMP(12);
 
-  // ---- c. greedy resolve on wave 0 (scalar registers) ---------------------------------------------
-  // Only a row's OWN column-group word feeds the serial chain (it decides who is alive later in the same
-  // group); the words for later groups are OR-ed into L.dead[] once per group by the kept lanes.
+  // ---- c. greedy resolve on wave 0, one 64-candidate group at a time, in parallel rounds ------------------
+  // Lane i knows which earlier rows of its group suppress it (col).  A candidate hit by a KEPT row is removed; a
+  // candidate none of whose still-undecided earlier rows suppresses it is kept (whatever those rows turn out to be, they
+  // do not touch it).  The lowest undecided candidate always falls in one of the two classes, so every round makes
+  // progress; the fixed point is the sequential greedy result, reached in (longest suppression chain) rounds.
   if (w == 0) {
+    unsigned long long deadw[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) deadw[g] = uniform64(L.dead[g]);
     int cnt = nk;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int left = nc - g * 64;
       if (left > 0 && cnt < R) {  // wave-uniform
-        unsigned long long rem = uniform64(L.dead[g]);
-        unsigned long long row[G];
-#pragma unroll
-        for (int w2 = 0; w2 < G; ++w2)
-          row[w2] = (w2 >= g && w2 * 64 < nc) ? L.mask[(g * 64 + lane) * G + w2] : 0ull;
-        const unsigned long long own = row[g];
-        // rows that suppress nothing inside the group are accepted in bulk: only the others need a serial step
-        const unsigned long long nz = __ballot(own != 0ull);
         const unsigned long long valid = (left >= 64) ? ~0ull : ((1ull << left) - 1ull);
-        unsigned long long alive = uniform64(~rem & valid);
+        const unsigned long long col = L.mask[(g * 64 + lane) * G + g];
+        unsigned long long und = ~deadw[g] & valid;
         unsigned long long keptbits = 0ull;
-        while (alive != 0ull && cnt < R) {
-          const unsigned long long nza = alive & nz;
-          const int f = (nza != 0ull) ? (int)__builtin_ctzll(nza) : 64;
-          unsigned long long batch = (f >= 64) ? alive : (alive & ((1ull << f) - 1ull));
-          int nb = __popcll(batch);
-          if (nb > 0) {
-            if (cnt + nb > R) {  // keep only the first R - cnt of them
-              unsigned long long t = 0ull, bb = batch;
-              for (int k = cnt; k < R; ++k) {
-                const unsigned long long low = bb & (0ull - bb);
-                t |= low;
-                bb ^= low;
-              }
-              batch = t;
-              nb = R - cnt;
-            }
-            keptbits |= batch;
-            cnt += nb;
-            alive &= ~batch;
-            if (cnt >= R) break;
-          }
-          if (f < 64) {
-            keptbits |= (1ull << f);
-            ++cnt;
-            rem |= readlane64(own, f);
-            alive &= ~(rem | keptbits);
-          }
+        while (und != 0ull) {
+          const bool in1 = (und >> lane) & 1ull;
+          und &= ~ballot64(in1 && (col & keptbits) != 0ull);
+          const bool in2 = (und >> lane) & 1ull;
+          const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
+          keptbits |= k;
+          und &= ~k;
         }
-        if ((keptbits >> lane) & 1ull) {
+        if (cnt + __popcll(keptbits) > R) {  // the greedy scan stops at R: keep the first R - cnt of them
+          unsigned long long t = 0ull, bb = keptbits;
+          for (int k = cnt; k < R; ++k) {
+            const unsigned long long low = bb & (0ull - bb);
+            t |= low;
+            bb ^= low;
+          }
+          keptbits = t;
+        }
+        // the kept rows suppress into the later groups of the chunk
 #pragma unroll
-          for (int w2 = 0; w2 < G; ++w2)
-            if (w2 > g && row[w2] != 0ull) atomicOr(&L.dead[w2], row[w2]);
-          const int pos = nk + __popcll(keptbits & lanemask_lt());
+        for (int w2 = g + 1; w2 < G; ++w2)
+          if (w2 * 64 < nc) deadw[w2] |= ballot64((L.mask[(w2 * 64 + lane) * G + g] & keptbits) != 0ull);
+        if ((keptbits >> lane) & 1ull) {
+          const int pos = cnt + __popcll(keptbits & lanemask_lt());
           const int j = g * 64 + lane;
           L.k_box[pos] = L.c_box[j];
           L.k_af[pos] = L.c_af[j];
           L.k_idx[pos] = L.c_idx[j];
         }
-        nk += __popcll(keptbits);
+        cnt += __popcll(keptbits);
       }
     }
-    if (lane == 0) L.s_nk[0] = nk;
+    if (lane == 0) L.s_nk[0] = cnt;
   }
   __syncthreads();
   FRCNN_STAMP(13);
