@@ -147,8 +147,26 @@ __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc
     FRCNN_STAMP(3);
     if (V > S) V = S;  // defensive; V == s_now by construction
     // ---- 3. order the slice ----------------------------------------------------------------------------
-    block_sort_perm(keys, permA, S, V, hist, wsum);
-    const uint16_t *perm = permA;
+    // Every key of the slice lies in [lowest key of the slice, T2]: the bits above the highest one in which the two ends
+    // differ are common to the whole slice, so the LSD sort only needs the passes below it (scores of one slice share the
+    // exponent and the first mantissa bits: 3 passes instead of 4).
+    __syncthreads();  // the compacted keys
+    uint32_t kmin = 0xFFFFFFFFu;
+    for (int j = tid; j < V; j += kNT) kmin = keys[j] < kmin ? keys[j] : kmin;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)kmin, off, 64);
+      kmin = o < kmin ? o : kmin;
+    }
+    if ((tid & 63) == 0) wsum[tid >> 6] = (int)kmin;  // (free: the barrier above is past the compaction's scans)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kNW; ++i) kmin = (uint32_t)wsum[i] < kmin ? (uint32_t)wsum[i] : kmin;
+    const uint32_t diff = kmin ^ T2;
+    const int npass = (V > 1 && diff) ? (32 - __builtin_clz(diff) + 7) / 8 : 1;
+    const int soff = block_sort_digits([&](int slot, int pass) -> uint32_t { return keys[slot] >> (8 * pass); }, npass, permA, S,
+                                       V, hist, wsum);
+    const uint16_t *perm = permA + soff;
     FRCNN_STAMP(4);
     // ---- 4. greedy NMS over the slice ------------------------------------------------------------------
     for (int cbase = 0; cbase < V && nk < R; cbase += CH) {
