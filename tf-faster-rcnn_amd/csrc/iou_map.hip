@@ -222,13 +222,19 @@ __global__ __launch_bounds__(256) void iou_map_rows_kernel(const float *__restri
 }
 
 // ---- fused reductions -----------------------------------------------------------------------
+// Maximum over the 64 lanes, returned to all of them (wave-uniform).  DPP steps inside the rows of 16 lanes, row
+// broadcasts across them, one v_readlane: about ten VALU instructions, against six dependent ds_bpermute round trips for a
+// shuffle butterfly (this runs once per (wave, gt) pair that has an overlap; an LDS 64-bit max per lane on the shared
+// column key was tried instead and doubled the kernel's time).
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-    v = (o > v) ? o : v;
-  }
-  return v;
+  auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1, 3
+  v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // One box against every gt of its image (row max / first argmax in registers, column keys merged in LDS).
