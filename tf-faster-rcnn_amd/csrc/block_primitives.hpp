@@ -16,11 +16,7 @@ static const int kNW = 16;
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int inc = v;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    int t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
-  }
+  inc = wave_incl_scan(inc);
   __syncthreads();  // wsum may still be read from a previous call
   if (lane == 63) wsum[w] = inc;
   __syncthreads();
@@ -99,11 +95,7 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
       const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
       const uint32_t s4 = h0 + h1 + h2 + h3;
       uint32_t inc = s4;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
-        if (lane >= off) inc += t;
-      }
+      inc = wave_incl_scan(inc);
       const uint32_t exc = inc - s4;
       const bool here = (exc < (uint32_t)need) && (inc >= (uint32_t)need);
       const unsigned long long bal = __ballot(here);

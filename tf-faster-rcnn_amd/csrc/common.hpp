@@ -196,6 +196,18 @@ __device__ __forceinline__ float4 encode_box(float4 bx, float4 g) {
 // back; this form takes the predicate as it is.
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
+// Inclusive prefix sum over the 64 lanes with DPP: row_shr 1/2/4/8 inside the rows of 16 lanes, then the row totals
+// carried over with row_bcast:15 / row_bcast:31 -- six v_add_u32_dpp instead of six dependent ds_bpermute round trips.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source add 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // ---- bare hardware max / min ------------------------------------------------------------------------
 // __builtin_fmaxf / fminf lower to llvm.maxnum / minnum, which in IEEE mode canonicalise both inputs first (a v_max_f32
 // x, x each): three instructions per max.  Where the caller has established that neither operand is NaN the bare

@@ -183,11 +183,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     const int c0 = ccount[4 * lane], c1 = ccount[4 * lane + 1], c2 = ccount[4 * lane + 2], c3 = ccount[4 * lane + 3];
     int inc = c0 + c1 + c2 + c3;
     const int s4 = inc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
+    inc = wave_incl_scan(inc);
     const int ex = inc - s4;
     cstart[4 * lane] = ex;
     cstart[4 * lane + 1] = ex + c0;
@@ -324,11 +320,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     const int c0 = kcount[4 * lane], c1 = kcount[4 * lane + 1], c2 = kcount[4 * lane + 2], c3 = kcount[4 * lane + 3];
     int inc = c0 + c1 + c2 + c3;
     const int s4 = inc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
+    inc = wave_incl_scan(inc);
     const int ex = inc - s4;
     koff[4 * lane] = ex;
     koff[4 * lane + 1] = ex + c0;

@@ -79,11 +79,7 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
       const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
       const uint32_t s4 = h0 + h1 + h2 + h3;
       uint32_t inc = s4;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)inc, off, 64);
-        if (lane >= off) inc += t;
-      }
+      inc = (uint32_t)wave_incl_scan((int)inc);
       const uint32_t exc = inc - s4;
       if ((exc < (uint32_t)need) && (inc >= (uint32_t)need)) {  // exactly one lane (S < N)
         uint32_t cum = exc;
