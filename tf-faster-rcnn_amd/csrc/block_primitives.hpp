@@ -39,11 +39,11 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool vali
   bool pend = valid;
 #pragma unroll
   for (int round = 0; round < 2; ++round) {
-    const unsigned long long act = __ballot(pend);
+    const unsigned long long act = ballot64(pend);
     if (act == 0ull) return;  // wave-uniform
     const int first = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(act));
     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)bin, first);
-    const unsigned long long same = __ballot(pend && (bin == b0));
+    const unsigned long long same = ballot64(pend && (bin == b0));
     if (lane_id() == first) atomicAdd(&hist[b0], (uint32_t)__popcll(same));
     pend = pend && (bin != b0);
   }
@@ -98,7 +98,7 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
       inc = wave_incl_scan(inc);
       const uint32_t exc = inc - s4;
       const bool here = (exc < (uint32_t)need) && (inc >= (uint32_t)need);
-      const unsigned long long bal = __ballot(here);
+      const unsigned long long bal = ballot64(here);
       if (bal == 0ull) {
         if (lane == 0) misc[2] = 1;
       } else if (here) {
@@ -175,11 +175,11 @@ __device__ __forceinline__ int block_sort_digits(DigitF digit, int npass, uint16
       const bool valid = p < V;
       const uint32_t id = valid ? (uint32_t)perm[src + p] : 0u;
       const uint32_t d = digit((int)id, pass) & 255u;
-      unsigned long long peers = __ballot(valid);
+      unsigned long long peers = ballot64(valid);
 #pragma unroll
       for (int bit = 0; bit < 8; ++bit) {
         const bool on = (d >> bit) & 1u;
-        const unsigned long long bm = __ballot(on);
+        const unsigned long long bm = ballot64(on);
         peers &= on ? bm : ~bm;
       }
       if (valid) {

@@ -234,13 +234,13 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
           bool irr = false, dd = false;
 #pragma unroll
           for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], p.iou, irr);
-          if (__builtin_expect(__any(irr || p.iou.slow_only), 0)) {
+          if (__builtin_expect(ballot64(irr || p.iou.slow_only) != 0ull, 0)) {
             dd = false;
 #pragma unroll
             for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), p.iou.thr);
           }
           d = d | dd;
-          if (__all(d || (lane >= nc))) break;
+          if (ballot64(!(d || (lane >= nc))) == 0ull) break;
         }
         // b. intra-tile mask: row i suppresses column lane (i < lane)
         unsigned long long own = 0ull;
@@ -252,19 +252,19 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
           bool bit[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, p.iou, irr);
-          if (__builtin_expect(__any(irr || p.iou.slow_only), 0)) {
+          if (__builtin_expect(ballot64(irr || p.iou.slow_only) != 0ull, 0)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), p.iou.thr);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const unsigned long long word = __ballot(bit[u] & (i0 + u < lane) & (lane < nc));
+            const unsigned long long word = ballot64(bit[u] & (i0 + u < lane) & (lane < nc));
             if (lane == i0 + u) own = word;
           }
         }
         // c. greedy resolve (scalar), rows that suppress nothing are accepted in bulk
-        const unsigned long long rem0 = __ballot(d);
-        const unsigned long long nz = __ballot(own != 0ull);
+        const unsigned long long rem0 = ballot64(d);
+        const unsigned long long nz = ballot64(own != 0ull);
         const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
         unsigned long long rem = uniform64(rem0);
         unsigned long long alive = uniform64(~rem & valid);

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void iou_map_kernel(const float *__restrict__ 
       const f32x4 gx2 = *reinterpret_cast<const f32x4 *>(lds + 3 * Mp + m0);
       const f32x4 ga = *reinterpret_cast<const f32x4 *>(lds + 4 * Mp + m0);
       f32x4 v;
-      if (!gt_nan && __ballot(barea != barea) == 0ull) {  // wave-uniform: no NaN coordinate anywhere in this wave's pairs
+      if (!gt_nan && ballot64(barea != barea) == 0ull) {  // wave-uniform: no NaN coordinate anywhere in this wave's pairs
         v.x = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.x, gx1.x, gy2.x, gx2.x, ga.x);
         v.y = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.y, gx1.y, gy2.y, gx2.y, ga.y);
         v.z = iou_pair<true>(bx.x, bx.y, bx.z, bx.w, barea, gy1.z, gx1.z, gy2.z, gx2.z, ga.z);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void iou_map_rows_kernel(const float *__restri
   const int W = M >> 2;
   f32x4 *__restrict__ orow = reinterpret_cast<f32x4 *>(out + ((long long)b * N + (live ? n : 0)) * M);
   // no NaN coordinate among this wave's boxes or the image's gts (a NaN coordinate makes the area NaN)
-  const bool nonan = !gt_nan && __ballot(barea != barea) == 0ull;
+  const bool nonan = !gt_nan && ballot64(barea != barea) == 0ull;
   for (int q0 = 0; q0 < W; q0 += 4) {
     const int q = q0 + qsub;
     const bool ok = live && q < W;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void iou_map_rows_kernel(const float *__restri
       const float isum = (in[0] + in[1]) + (in[2] + in[3]);
       const float umin = hw_min(hw_min(un[0], un[1]), hw_min(un[2], un[3]));
       const bool trivial = (isum == 0.0f) && (umin > 0.0f);  // +0 / positive = +0 for all four
-      if (__ballot(ok && !trivial) == 0ull) {
+      if (ballot64(ok && !trivial) == 0ull) {
         v = (f32x4)(0.0f);
       } else {
         v.x = in[0] / un[0];
@@ -241,14 +241,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 template <bool NONAN>
 __device__ __forceinline__ void reduce_row(const float *lds, int Mp, int M, float4 bx, float barea, bool live, int n,
                                            bool want_cols, unsigned long long *colk, float &best, float &mx, int &am) {
-  const unsigned long long live_mask = __ballot(live);
+  const unsigned long long live_mask = ballot64(live);
   for (int m = 0; m < M; ++m) {
     float inter, uni;
     iou_terms<NONAN>(bx.x, bx.y, bx.z, bx.w, barea, lds[m], lds[Mp + m], lds[2 * Mp + m], lds[3 * Mp + m], lds[4 * Mp + m],
                      inter, uni);
     // Zero-padded gts and gts far from this wave's 64 neighbouring boxes intersect none of them: the quotient is exactly
     // +0 for every lane (inter == +0, union > 0), so the divide and the cross-lane maximum are skipped (wave-uniform).
-    const bool all_zero = NONAN && __ballot(live && !(inter == 0.0f && uni > 0.0f)) == 0ull;
+    const bool all_zero = NONAN && ballot64(live && !(inter == 0.0f && uni > 0.0f)) == 0ull;
     const float v = all_zero ? 0.0f : inter / uni;
     if (v > best) {
       best = v;
@@ -267,7 +267,7 @@ __device__ __forceinline__ void reduce_row(const float *lds, int Mp, int M, floa
       // key 0 = "no candidate" (dead lanes, NaN, and anything not above lowest()).
       uint32_t k = (live && v > -3.402823466e+38f) ? f_order_key(v) : 0u;
       const uint32_t wmax = wave_max_u32(k);
-      const unsigned long long hit = __ballot(k == wmax);
+      const unsigned long long hit = ballot64(k == wmax);
       if (wmax != 0u && lane_id() == (int)__builtin_ctzll(hit)) {
         const unsigned long long key = ((unsigned long long)wmax << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
         atomicMax(&colk[m], key);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void iou_reduce_kernel(const float *__restrict
   // [TF-recall] Eigen ArgMax / Max reducers: strict '>' starting from lowest().
   float best = -3.402823466e+38f, mx = -3.402823466e+38f;
   int am = 0;
-  if (!gt_nan && __ballot(barea != barea) == 0ull)  // wave-uniform: no NaN coordinate in this wave's boxes or the gts
+  if (!gt_nan && ballot64(barea != barea) == 0ull)  // wave-uniform: no NaN coordinate in this wave's boxes or the gts
     reduce_row<true>(lds, Mp, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
   else
     reduce_row<false>(lds, Mp, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void bm_prepare_kernel(BitmaskParams p) {
   }
   p.pbox[(long long)b * Kp + j] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
   p.paf[(long long)b * Kp + j] = make_float2(nb.area, __int_as_float(fl));
-  const unsigned long long badw = __ballot(bad);
+  const unsigned long long badw = ballot64(bad);
   if (lane == 0) {
     p.removed[(long long)b * p.nb + blk] = badw;
     if (blk == 0) {
@@ -101,7 +101,7 @@ __device__ __forceinline__ unsigned long long tile_column_word(const float4 *row
     bool bit[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rbx[u], me, thr, irr);
-    if (__builtin_expect(__any(irr || thr.slow_only), 0)) {
+    if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rbx[u]), to_nbox(me), thr.thr);
     }
@@ -235,9 +235,9 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
       unsigned long long keptbits = 0ull;
       while (und != 0ull) {
         const bool in1 = (und >> lane) & 1ull;
-        und &= ~__ballot(in1 && (col & keptbits) != 0ull);
+        und &= ~ballot64(in1 && (col & keptbits) != 0ull);
         const bool in2 = (und >> lane) & 1ull;
-        const unsigned long long k = __ballot(in2 && (col & und) == 0ull);
+        const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
         keptbits |= k;
         und &= ~k;
       }

@@ -181,7 +181,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
     L.c_box[tid] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
     L.c_af[tid] = make_float2(nb.area, __int_as_float(fl));
     L.c_idx[tid] = ei;
-    const unsigned long long badw = __ballot(bad);  // candidates that fail the score threshold start dead
+    const unsigned long long badw = ballot64(bad);  // candidates that fail the score threshold start dead
     if (lane == 0) L.dead[w] = badw;
   }
   for (int i = tid; i < CH * G; i += NT) L.mask[i] = 0ull;  // column words, OR-ed together in phase b
@@ -206,13 +206,13 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
         bool irr = false, dd = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], thr, irr);
-        if (__builtin_expect(__any(irr || thr.slow_only), 0)) {
+        if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
           dd = false;
 #pragma unroll
           for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), thr.thr);
         }
         d = d | dd;
-        if (__all(d || (j >= nc))) break;
+        if (ballot64(!(d || (j >= nc))) == 0ull) break;
       }
       const unsigned long long word = ballot64(d && (j < nc));
       if (lane == 0 && word != 0ull) atomicOr(&L.dead[j >> 6], word);
@@ -255,7 +255,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       bool bit[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, thr, irr);
-      if (__builtin_expect(__any(irr || thr.slow_only), 0)) {
+      if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), thr.thr);
       }
