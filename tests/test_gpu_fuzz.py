@@ -49,6 +49,29 @@ def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
         assert_bits(got, want, f"RoIBBox fuzz case {case}: {schedule} B={B} G={G} K={K} R={R} thr={thr}")
 
 
+def test_roi_bbox_minus_inf_scores_all_schedules(pkg, monkeypatch):
+    """Scores of -inf never pass combined_non_max_suppression's strict `score > -inf`: with more than N - K of them the
+    top-K holds dead candidates, which every schedule must skip (and NaN-free ties between them order by index)."""
+    rng = np.random.default_rng(99)
+    for case, schedule in enumerate(("fused", "bitmask", "unfused") * 3):
+        monkeypatch.delenv("FRCNN_ROI_BBOX_UNFUSED", raising=False)
+        monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
+        if schedule == "unfused":
+            monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+        G, K, R = 12, 1000, (40, 400, 1200)[case // 3]
+        hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+        hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R)
+        anchors = oracle.generate_anchors(hp)
+        deltas, scores = synth.rpn_outputs(500 + case, 3, G)
+        scores = scores.reshape(3, -1).copy()
+        scores[rng.random(scores.shape) < 0.6] = -np.inf   # 1296 anchors, ~520 finite: fewer than K
+        scores[2] = -np.inf                                 # an image with nothing to keep
+        got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+        want, _, valid = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, 0.7, return_all=True)
+        assert valid[2] == 0
+        assert_bits(got, want, f"RoIBBox -inf scores: {schedule} R={R}")
+
+
 def test_fuzz_roi_pooling(pkg, monkeypatch):
     rng = np.random.default_rng(7)
     for case in range(240):

@@ -5,19 +5,21 @@
 // models/faster_rcnn.py:158-164 (RoIBBox: 1 class, IoU 0.7, R outputs) and :84-90 (Decoder:
 // L classes, score > 0.5, IoU 0.5, 200 outputs).
 //
-// Algorithm (one workgroup per segment = (image, class), 4..16 waves):
+// Algorithm (one workgroup per segment = (image, class), 4..16 waves; nms_core.hpp):
 //   candidates arrive ordered by (score desc, index asc) from sort_select.  They are consumed in
-//   chunks of 256.  For a chunk:
+//   chunks of 64..256.  For a chunk:
 //     a. every candidate is tested against the list of boxes kept so far (LDS, broadcast reads);
-//        the 64 verdicts of a wave become one 64-bit "dead" word by __ballot;
-//     b. the chunk's own 256x256 upper-triangular suppression matrix is built as IoU tiles of
-//        64 rows x 64 columns: lane = column box, the row box is broadcast from LDS, and one
-//        __ballot per row yields the 64-bit mask word mask[row][column group] in LDS;
-//     c. wave 0 resolves the greedy order on scalar registers: pick the lowest alive bit, OR that
-//        row's mask words (v_readlane) into the removed set, repeat; kept boxes are appended to the
-//        kept list.
+//        the 64 verdicts of a wave become one 64-bit "dead" word by a wave vote;
+//     b. the chunk's own upper-triangular suppression matrix is built as IoU tiles of 64 rows x 64
+//        columns: lane = column box, the row box is broadcast from LDS, and the lane collects "row r
+//        suppresses me" into a 64-bit COLUMN word (rows that are already dead are skipped);
+//     c. wave 0 resolves the greedy order one 64-candidate group at a time in parallel rounds (a candidate
+//        hit by a kept row is removed; one with no undecided earlier suppressor is kept), marks the
+//        columns its kept rows suppress in the later groups with one vote each, and appends the kept
+//        boxes to the kept list.
 //   The scan stops as soon as R boxes are kept, so the work is ~(kept x scanned) IoU tests instead of
-//   the K^2/2 of a full bitmask, and nothing but the final boxes ever leaves the CU.
+//   the K^2/2 of a full bitmask, and nothing but the final boxes ever leaves the CU.  (For large R the
+//   pair tests go to the whole chip instead: nms_bitmask.hip.)
 //   Greedy NMS is inherently serial in the kept list; this kernel is latency/ALU bound and is judged on
 //   images/s, not GB/s.
 //
