@@ -151,3 +151,45 @@ def test_band_filter_never_contradicts_the_division(thr):
     assert not (yes & ~ref).any() and not (no & ref).any()
     assert not (yes & no).any()
     assert (~(yes | no)).mean() < 0.5  # the band is narrow: most near-threshold pairs are still decided
+
+
+# ---- the parallel-round resolve of a 64-candidate block (nms_core.hpp phase c, nms_bitmask.hip scan), restated ----------
+def _greedy_block(sup, alive):
+    """Sequential greedy NMS inside a block: sup[r][c] = row r suppresses column c (r < c); alive = candidates not yet dead."""
+    kept, removed = [], set()
+    for i in range(len(sup)):
+        if i in alive and i not in removed:
+            kept.append(i)
+            removed.update(c for c in range(i + 1, len(sup)) if sup[i][c])
+    return kept
+
+
+def _rounds_block(sup, alive):
+    """The kernels' form: a candidate hit by a KEPT row is removed; a candidate none of whose still-undecided earlier rows
+    suppresses it is kept; repeat until nobody is undecided."""
+    n = len(sup)
+    col = [{r for r in range(c) if sup[r][c]} for c in range(n)]
+    und, kept, rounds = set(alive), set(), 0
+    while und:
+        rounds += 1
+        und -= {c for c in und if col[c] & kept}
+        new = {c for c in und if not (col[c] & und)}
+        assert new or not und  # progress: the lowest undecided candidate is always decided
+        kept |= new
+        und -= new
+    return sorted(kept), rounds
+
+
+@pytest.mark.parametrize("density", [0.0, 0.02, 0.1, 0.4, 0.9])
+def test_parallel_round_resolve_equals_sequential_greedy(density):
+    rng = np.random.default_rng(int(density * 100))
+    worst = 0
+    for _ in range(200):
+        n = int(rng.integers(1, 65))
+        sup = np.triu(rng.random((n, n)) < density, 1)
+        alive = set(np.flatnonzero(rng.random(n) < 0.8).tolist())
+        want = _greedy_block(sup, alive)
+        got, rounds = _rounds_block(sup, alive)
+        assert got == want
+        worst = max(worst, rounds)
+    assert worst <= 64
