@@ -49,7 +49,7 @@ def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
         assert_bits(got, want, f"RoIBBox fuzz case {case}: {schedule} B={B} G={G} K={K} R={R} thr={thr}")
 
 
-def wip_roi_bbox_minus_inf_scores_all_schedules(pkg, monkeypatch):
+def test_roi_bbox_minus_inf_scores_all_schedules(pkg, monkeypatch):
     """Scores of -inf never pass combined_non_max_suppression's strict `score > -inf`: with more than N - K of them the
     top-K holds dead candidates, which every schedule must skip (and NaN-free ties between them order by index)."""
     rng = np.random.default_rng(99)
