@@ -81,6 +81,7 @@ def test_fuzz_roi_pooling(pkg, monkeypatch):
         R = int(rng.integers(1, 40))
         ph, pw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
         monkeypatch.setenv("FRCNN_CROP_SLICE", str(case % 2))
+        monkeypatch.setenv("FRCNN_CROP_ROWS", str((case // 2) % 2))  # (box, output row) workgroups (diagnostic schedule)
         fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
         rois = rng.uniform(-0.2, 1.2, (B, R, 4)).astype(np.float32)  # inverted and out-of-image boxes included
         hp = synth.hyper_params(pooling_size=(ph, pw))

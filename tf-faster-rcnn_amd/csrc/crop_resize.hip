@@ -198,11 +198,14 @@ __global__ __launch_bounds__(256) void crop_resize_slice_kernel(
 #ifndef FRCNN_CROP_WAVES_PER_EU
 #define FRCNN_CROP_WAVES_PER_EU 4
 #endif
-template <int VEC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FRCNN_CROP_WAVES_PER_EU, FRCNN_CROP_WAVES_PER_EU)))
+// ROWS = false: one workgroup per box (all ch*cw output pixels); ROWS = true: one workgroup per (box, output row), i.e.
+// cw pixels = 16 KB at 7 x 576 -- a single trip of 4 outputs per lane, seven times as many workgroups and a tighter
+// write front.  `units` = number of workgroups' worth of work (n or n*ch).
+template <int VEC, bool ROWS, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void crop_resize_kernel(
     const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
-    const int *__restrict__ box_ind, int n, int boxes_per_image, int ch, int cw, float extrap,
+    const int *__restrict__ box_ind, int units, int boxes_per_image, int ch, int cw, float extrap,
     float *__restrict__ out) {
   typedef typename VecT<VEC>::type vec_t;
   __shared__ PixParam pp[256];
@@ -212,9 +215,11 @@ void crop_resize_kernel(
   const int tid = threadIdx.x;
   const int grp = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
-  const int q = n >> 3, r = n & 7;
+  const int q = units >> 3, r = units & 7;
   const int start = (grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q;
-  const int box = start + slot;
+  const int unit = start + slot;
+  const int box = ROWS ? unit / ch : unit;
+  const int pbeg = ROWS ? (unit - box * ch) * cw : 0;  // first output pixel of this workgroup
 
   const int bimg = box_ind ? box_ind[box] : (box / boxes_per_image);
   const bool img_ok = (bimg >= 0) && (bimg < B);
@@ -224,19 +229,19 @@ void crop_resize_kernel(
   const float x2 = boxes[(long long)box * 4 + 3];
 
   const int CV = C / VEC;
-  const int P = ch * cw;
+  const int P = ROWS ? cw : ch * cw;  // output pixels of this workgroup
   const vec_t *__restrict__ img =
       reinterpret_cast<const vec_t *>(image + (long long)(img_ok ? bimg : 0) * H * W * C);
 
   for (int p0 = 0; p0 < P; p0 += 256) {
     const int np = (P - p0 < 256) ? (P - p0) : 256;
     if (p0 > 0) __syncthreads();
-    if (tid < np) pp[tid] = pix_param(p0 + tid, H, W, (unsigned)C * 4u, ch, cw, y1, x1, y2, x2, img_ok);
+    if (tid < np) pp[tid] = pix_param(pbeg + p0 + tid, H, W, (unsigned)C * 4u, ch, cw, y1, x1, y2, x2, img_ok);
     __syncthreads();
 
     const int total = np * CV;
     const char *__restrict__ base = reinterpret_cast<const char *>(img);
-    char *__restrict__ dstb = reinterpret_cast<char *>(out + ((long long)box * P + p0) * C);
+    char *__restrict__ dstb = reinterpret_cast<char *>(out + ((long long)box * ch * cw + pbeg + p0) * C);
     int p = tid / CV;
     int c = tid - p * CV;
     const int dp = 256 / CV, dc = 256 - dp * CV;
@@ -311,14 +316,19 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
                        boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out, SW);
     return check_launch("crop_and_resize");
   }
-  if (vec4) {
-    hipLaunchKernelGGL(crop_resize_kernel<4>, grid, block, 0, (hipStream_t)stream, image, B, H, W,
-                       C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value,
-                       out);
+  // FRCNN_CROP_ROWS=0|1 forces the (box) / (box, output row) decomposition (diagnostic).
+  const char *rows_env = getenv("FRCNN_CROP_ROWS");
+  const bool rows_fit = (long long)n * crop_h < (1ll << 31);
+  const bool use_rows = vec4 && rows_fit && (rows_env ? atoi(rows_env) != 0 : false);
+  if (use_rows) {
+    hipLaunchKernelGGL((crop_resize_kernel<4, true, 6>), dim3((unsigned)(n * crop_h)), block, 0, (hipStream_t)stream, image,
+                       B, H, W, C, boxes, box_ind, n * crop_h, boxes_per_image, crop_h, crop_w, extrapolation_value, out);
+  } else if (vec4) {
+    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, image,
+                       B, H, W, C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out);
   } else {
-    hipLaunchKernelGGL(crop_resize_kernel<1>, grid, block, 0, (hipStream_t)stream, image, B, H, W,
-                       C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value,
-                       out);
+    hipLaunchKernelGGL((crop_resize_kernel<1, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, image,
+                       B, H, W, C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out);
   }
   return check_launch("crop_and_resize");
 }

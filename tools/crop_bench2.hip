@@ -1,0 +1,299 @@
+// crop_bench2.hip -- A/B of crop_and_resize work decompositions whose WRITE FRONT is compact (diagnostic; not part of the
+// library).  crop_bench.hip showed that the store pattern alone moves the sustained ceiling from 5.3 TB/s (one 110 KB
+// region per workgroup) to 6.9 TB/s (4 KB per workgroup, workgroups in address order).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/crop_bench2.hip -o tools/diag/crop_bench2
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#include "../tf-faster-rcnn_amd/csrc/crop_resize.hip"
+#include "../tf-faster-rcnn_amd/csrc/api.hip"
+
+// ---- pre-pass: sampling parameters of every output pixel, offsets relative to the whole feature tensor ----------------
+__global__ __launch_bounds__(256) void params_kernel(int B, int H, int W, int C, const float *__restrict__ boxes, int n,
+                                                     int boxes_per_image, int ch, int cw, PixParam *__restrict__ params) {
+  const int gp = blockIdx.x * 256 + threadIdx.x;
+  const int P = ch * cw;
+  if (gp >= n * P) return;
+  const int box = gp / P, p = gp - box * P;
+  const int bimg = box / boxes_per_image;
+  const bool img_ok = bimg >= 0 && bimg < B;
+  const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + (long long)box * 4);
+  PixParam prm = pix_param(p, H, W, (unsigned)C * 4u, ch, cw, bx.x, bx.y, bx.z, bx.w, img_ok);
+  const unsigned ib = (unsigned)(img_ok ? bimg : 0) * (unsigned)(H * W * C) * 4u;
+  prm.off_tl += ib;
+  prm.off_tr += ib;
+  prm.off_bl += ib;
+  prm.off_br += ib;
+  params[gp] = prm;
+}
+
+// ---- tile kernel: workgroup = 256*U consecutive float4 of the output, workgroups in address order ----------------------
+// MAP 0: tile = blockIdx; MAP 1: each XCD (blockIdx % 8) owns one contiguous eighth of the tiles.
+template <int CV, int U, int MAP, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void crop_tile_kernel(const char *__restrict__ image, const PixParam *__restrict__ params, f32x4 *__restrict__ out,
+                      unsigned n4, unsigned ntiles, float extrap) {
+  unsigned tile = blockIdx.x;
+  if (MAP == 1) {
+    const unsigned grp = tile & 7, slot = tile >> 3;
+    const unsigned q = ntiles >> 3, r = ntiles & 7;
+    tile = ((grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + slot;
+  }
+  const unsigned e0 = tile * (256u * U) + threadIdx.x;
+  f32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned e = e0 + u * 256u;
+    e = e < n4 ? e : n4 - 1;
+    const unsigned gp = e / CV, c = e - gp * CV;
+    const unsigned gpw = __builtin_amdgcn_readfirstlane(gp);
+    const PixParam *pa = params + gpw;  // wave-uniform: scalar loads
+    const PixParam a = pa[0], b = pa[1];
+    const bool second = gp != gpw;      // CV >= 64: a wave spans at most two pixels
+    PixParam prm;
+    prm.off_tl = second ? b.off_tl : a.off_tl;
+    prm.off_tr = second ? b.off_tr : a.off_tr;
+    prm.off_bl = second ? b.off_bl : a.off_bl;
+    prm.off_br = second ? b.off_br : a.off_br;
+    prm.lx = second ? b.lx : a.lx;
+    prm.ly = second ? b.ly : a.ly;
+    prm.valid = second ? b.valid : a.valid;
+    v[u] = bilerp<f32x4>(image, prm, c * 16u, extrap);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned e = e0 + u * 256u;
+    if (e < n4) __builtin_nontemporal_store(v[u], &out[e]);
+  }
+}
+
+// ---- row kernel: workgroup = (box, output row): cw*CV contiguous float4 (16 KB at 7 x 576) ----------------------------
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void crop_row_kernel(const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes, int n,
+                     int boxes_per_image, int ch, int cw, float extrap, float *__restrict__ out) {
+  __shared__ PixParam pp[64];
+  const int tid = threadIdx.x;
+  const unsigned nrows = (unsigned)n * ch;
+  const unsigned grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const unsigned q = nrows >> 3, r = nrows & 7;
+  const unsigned row = ((grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + slot;
+  const int box = row / ch, y = row - box * ch;
+  const int bimg = box / boxes_per_image;
+  const bool img_ok = bimg >= 0 && bimg < B;
+  const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + (long long)box * 4);
+  if (tid < cw) pp[tid] = pix_param(y * cw + tid, H, W, (unsigned)C * 4u, ch, cw, bx.x, bx.y, bx.z, bx.w, img_ok);
+  __syncthreads();
+  const int CV = C >> 2;
+  const int total = cw * CV;
+  const char *__restrict__ base = reinterpret_cast<const char *>(image + (long long)(img_ok ? bimg : 0) * H * W * C);
+  char *__restrict__ dstb = reinterpret_cast<char *>(out + (long long)row * cw * C);
+  int p = tid / CV;
+  int c = tid - p * CV;
+  const int dp = 256 / CV, dc = 256 - dp * CV;
+  f32x4 v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const bool in = tid + u * 256 < total;
+    const PixParam prm = pp[in ? p : 0];
+    v[u] = bilerp<f32x4>(base, prm, (unsigned)(in ? c : 0) * 16u, extrap);
+    c += dc;
+    p += dp;
+    if (c >= CV) {
+      c -= CV;
+      ++p;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + u * 256;
+    if (e < total) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4 *>(dstb + (size_t)e * 16));
+  }
+}
+
+
+// ---- LDS-deduplicated chunk kernel: workgroup = (box, QC float4 channels) --------------------------------------------
+// The 4*ch*cw taps of a box are the cross product rows_used x cols_used (<= 2ch x 2cw, about 128 of 196 distinct on
+// RoI-like boxes).  Each distinct tap goes through the vector-memory path once (global -> LDS), the four taps of an
+// output pixel are ds_read_b128 (256 B/clk/CU against the 64 B/clk/CU of the texture-addresser path).
+template <int QC>
+__global__ __launch_bounds__(256) void crop_lds_kernel(const float *__restrict__ image, int B, int H, int W, int C,
+                                                       const float *__restrict__ boxes, int n, int boxes_per_image, int ch,
+                                                       int cw, float extrap, float *__restrict__ out, int nchunk) {
+  __shared__ f32x4 tile[14 * 14 * QC];
+  __shared__ int t_lo[32], t_hi[32], t_ok[32];  // [0,16): rows by y, [16,32): cols by x -- slots into the tile
+  __shared__ float t_fr[32];
+  __shared__ int t_list[32];                    // slot -> source row / col
+  __shared__ int t_cnt[2];
+  const int tid = threadIdx.x;
+  const unsigned nwg = (unsigned)n * nchunk;
+  const unsigned grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const unsigned q8 = nwg >> 3, r8 = nwg & 7;
+  const unsigned wg = ((grp < r8) ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + slot;
+  const int box = wg / nchunk, chunk = wg - box * nchunk;
+  const int bimg = box / boxes_per_image;
+  const bool img_ok = bimg >= 0 && bimg < B;
+  if (tid < 64) {
+    const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + (long long)box * 4);
+    const bool isx = (tid & 16) != 0;
+    const int i = tid & 15;
+    const int cn = isx ? cw : ch;
+    const float a1 = isx ? bx.y : bx.x, a2 = isx ? bx.w : bx.z;
+    const float lim = (float)((isx ? W : H) - 1);
+    float in;
+    if (cn > 1) {
+      float t = a2 - a1;
+      t = t * lim;
+      const float sc = t / (float)(cn - 1);
+      const float t0 = a1 * lim;
+      const float t1 = (float)i * sc;
+      in = t0 + t1;
+    } else {
+      float t0 = a1 + a2;
+      t0 = 0.5f * t0;
+      in = t0 * lim;
+    }
+    const bool ok = (tid < 32) && (i < cn) && img_ok && (in >= 0.0f) && (in <= lim);
+    const int lo = ok ? (int)floorf(in) : 0, hi = ok ? (int)ceilf(in) : 0;
+    const float fr = ok ? in - (float)lo : 0.0f;
+    unsigned long long m = ok ? ((1ull << lo) | (1ull << hi)) : 0ull;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      const unsigned lo32 = __shfl_xor((unsigned)m, off, 64), hi32 = __shfl_xor((unsigned)(m >> 32), off, 64);
+      m |= ((unsigned long long)hi32 << 32) | lo32;
+    }
+    if (tid < 32) {
+      t_lo[tid] = __popcll(m & ((1ull << lo) - 1ull));
+      t_hi[tid] = __popcll(m & ((1ull << hi) - 1ull));
+      t_ok[tid] = ok;
+      t_fr[tid] = fr;
+    }
+    const unsigned long long rmask = ((unsigned long long)__shfl((unsigned)(m >> 32), 0, 64) << 32) | __shfl((unsigned)m, 0, 64);
+    const unsigned long long cmask = ((unsigned long long)__shfl((unsigned)(m >> 32), 16, 64) << 32) | __shfl((unsigned)m, 16, 64);
+    if ((rmask >> tid) & 1ull) t_list[__popcll(rmask & ((1ull << tid) - 1ull))] = tid;
+    if ((cmask >> tid) & 1ull) t_list[16 + __popcll(cmask & ((1ull << tid) - 1ull))] = tid;
+    if (tid == 0) {
+      t_cnt[0] = __popcll(rmask);
+      t_cnt[1] = __popcll(cmask);
+    }
+  }
+  __syncthreads();
+  const int nr = t_cnt[0], nc = t_cnt[1];
+  const int CV = C >> 2;
+  const int c0 = chunk * QC;
+  const int cq = tid & (QC - 1);
+  const bool c_in = c0 + cq < CV;
+  const f32x4 *__restrict__ img = reinterpret_cast<const f32x4 *>(image + (long long)(img_ok ? bimg : 0) * H * W * C) + c0 + cq;
+  const int ntap = nr * nc;
+  for (int t = tid / QC; t < ntap; t += 256 / QC) {
+    const int ri = t / nc, ci = t - ri * nc;
+    const int row = t_list[ri], col = t_list[16 + ci];
+    if (c_in) tile[t * QC + cq] = img[(row * W + col) * CV];
+  }
+  __syncthreads();
+  const int P = ch * cw;
+  f32x4 *__restrict__ dst = reinterpret_cast<f32x4 *>(out + (long long)box * P * C) + c0 + cq;
+  for (int p = tid / QC; p < P; p += 256 / QC) {
+    const int y = p / cw, x = p - y * cw;
+    f32x4 v = (f32x4)(extrap);
+    if (t_ok[y] && t_ok[16 + x]) {
+      const int rt = t_lo[y] * nc, rb = t_hi[y] * nc, cl = t_lo[16 + x], cr = t_hi[16 + x];
+      const float ly = t_fr[y], lx = t_fr[16 + x];
+      const f32x4 tl = tile[(rt + cl) * QC + cq], tr = tile[(rt + cr) * QC + cq];
+      const f32x4 bl = tile[(rb + cl) * QC + cq], br = tile[(rb + cr) * QC + cq];
+      f32x4 t = vsub(tr, tl);
+      t = t * lx;
+      const f32x4 tp = tl + t;
+      t = vsub(br, bl);
+      t = t * lx;
+      const f32x4 bt = bl + t;
+      t = vsub(bt, tp);
+      t = t * ly;
+      v = tp + t;
+    }
+    if (c_in) __builtin_nontemporal_store(v, &dst[p * CV]);
+  }
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+template <class F>
+static float time_ms(F f, int iters) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) f();
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a));
+  for (int i = 0; i < iters; ++i) f();
+  CK(hipEventRecord(b));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+int main(int argc, char **argv) {
+  const int B = 16, H = 32, W = 32, C = 576, R = 300, n = B * R;
+  const long long out_floats = (long long)n * 49 * C;
+  float *img, *boxes, *out, *ref;
+  PixParam *params;
+  CK(hipMalloc(&img, (size_t)B * H * W * C * 4));
+  CK(hipMalloc(&boxes, (size_t)n * 16));
+  CK(hipMalloc(&out, (size_t)out_floats * 4));
+  CK(hipMalloc(&ref, (size_t)out_floats * 4));
+  CK(hipMalloc(&params, (size_t)(n * 49 + 1) * sizeof(PixParam)));
+  CK(hipMemset(params, 0, (size_t)(n * 49 + 1) * sizeof(PixParam)));
+  std::vector<float> hb(n * 4), hi((size_t)B * H * W * C);
+  srand(1);
+  // RoI-like boxes: sizes 0.15..0.7 of the image, some touching the border, a few zero-padded rows
+  for (int i = 0; i < n; ++i) {
+    float cy = rand() / (float)RAND_MAX, cx = rand() / (float)RAND_MAX;
+    float h = 0.15f + 0.55f * (rand() / (float)RAND_MAX), w = 0.15f + 0.55f * (rand() / (float)RAND_MAX);
+    hb[i * 4 + 0] = std::max(0.f, cy - h / 2); hb[i * 4 + 2] = std::min(1.f, cy + h / 2);
+    hb[i * 4 + 1] = std::max(0.f, cx - w / 2); hb[i * 4 + 3] = std::min(1.f, cx + w / 2);
+    if (i % 97 == 0) hb[i * 4 + 0] = hb[i * 4 + 1] = hb[i * 4 + 2] = hb[i * 4 + 3] = 0.f;
+  }
+  for (auto &v : hi) v = rand() / (float)RAND_MAX;
+  CK(hipMemcpy(boxes, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(img, hi.data(), hi.size() * 4, hipMemcpyHostToDevice));
+  const double bytes = (double)out_floats * 4;
+  const double alg = bytes + (double)B * H * W * C * 4 + n * 20.0;
+  const int iters = 30;
+  const unsigned n4 = (unsigned)(out_floats / 4);
+  std::vector<float> h_ref((size_t)out_floats), h_out((size_t)out_floats);
+
+  frcnn_crop_and_resize(img, B, H, W, C, boxes, nullptr, n, R, 7, 7, 0.f, ref, nullptr);
+  CK(hipMemcpy(h_ref.data(), ref, (size_t)out_floats * 4, hipMemcpyDeviceToHost));
+  auto check = [&](const char *name) {
+    CK(hipMemcpy(h_out.data(), out, (size_t)out_floats * 4, hipMemcpyDeviceToHost));
+    const bool same = memcmp(h_out.data(), h_ref.data(), (size_t)out_floats * 4) == 0;
+    printf("   %s: %s\n", name, same ? "bit-identical to the library kernel" : "MISMATCH");
+    CK(hipMemset(out, 0xff, (size_t)out_floats * 4));
+  };
+  float ms;
+  ms = time_ms([&] { frcnn_crop_and_resize(img, B, H, W, C, boxes, nullptr, n, R, 7, 7, 0.f, out, nullptr); }, iters);
+  printf("library box kernel                 %8.2f us  %7.1f GB/s\n", ms * 1e3, alg / ms / 1e6);
+  check("library");
+
+  auto prepass = [&] {
+    hipLaunchKernelGGL(params_kernel, dim3((n * 49 + 255) / 256), dim3(256), 0, 0, B, H, W, C, boxes, n, R, 7, 7, params);
+  };
+  ms = time_ms(prepass, iters);
+  printf("params pre-pass                    %8.2f us\n", ms * 1e3);
+
+#define LDSK(QC) { \
+    const int nchunk = (C / 4 + QC - 1) / QC; \
+    ms = time_ms([&] { hipLaunchKernelGGL((crop_lds_kernel<QC>), dim3(n * nchunk), dim3(256), 0, 0, img, B, H, W, C, boxes, n, R, 7, 7, 0.f, out, nchunk); }, iters); \
+    printf("lds dedupe kernel QC=%d              %8.2f us  %7.1f GB/s\n", QC, ms * 1e3, alg / ms / 1e6); \
+    check("lds"); }
+  LDSK(8) LDSK(16) LDSK(4)
+#define ROW(WPE) { \
+    ms = time_ms([&] { hipLaunchKernelGGL((crop_row_kernel<WPE>), dim3(n * 7), dim3(256), 0, 0, img, B, H, W, C, boxes, n, R, 7, 7, 0.f, out); }, iters); \
+    printf("row kernel wpe=%d                   %8.2f us  %7.1f GB/s\n", WPE, ms * 1e3, alg / ms / 1e6); \
+    check("row"); }
+  ROW(6)
+  return 0;
+}
