@@ -38,6 +38,7 @@ def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
         monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
         if schedule == "unfused":
             monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+        monkeypatch.setenv("FRCNN_PROPOSAL_THREADS", "256" if (case // 3) % 2 else "1024")  # block size of the fused kernel
         hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
         hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
         anchors = oracle.generate_anchors(hp)
@@ -97,6 +98,7 @@ def test_fuzz_decoder(pkg, monkeypatch):
         T = int(rng.integers(1, 300))
         thr = float(rng.choice([0.05, 0.3, 0.5, 0.8]))
         monkeypatch.setenv("FRCNN_DECODER_UNFUSED", str(case % 2))
+        monkeypatch.setenv("FRCNN_DECODER_THREADS", "256" if (case // 2) % 2 else "1024")  # block size of the fused kernel
         hp = synth.hyper_params()
         rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
         deltas = rng.normal(0, 0.5, (B, R, L * 4)).astype(np.float32)

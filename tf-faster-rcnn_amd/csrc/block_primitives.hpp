@@ -1,4 +1,5 @@
-// block_primitives.hpp -- workgroup-cooperative building blocks (1024 threads = 16 waves of 64):
+// block_primitives.hpp -- workgroup-cooperative building blocks (NT threads = NT/64 waves of 64; 1024 unless the caller
+// names another block size as the first template argument):
 // exclusive scan, wave-aggregated LDS histogram add, 4x8-bit radix SELECT and the stable LSD radix
 // SORT of 16-bit slot numbers.  Used by sort_select.hip, proposal.hip and rpn_targets.hip.
 //
@@ -13,7 +14,9 @@ static const int kNT = 1024;
 static const int kNW = 16;
 
 // Exclusive scan of one int per thread; `total` is returned to every thread.  wsum: kNW ints of LDS.
+template <int NT = kNT>
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
+  constexpr int kNW = NT / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int inc = v;
   inc = wave_incl_scan(inc);
@@ -54,9 +57,11 @@ __device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool vali
 // that the element of 1-based ascending rank `need` carries, and need_eq = how many elements equal to T
 // are inside the first `need` (to be taken in index order).  all = true when fewer than `need` valid
 // elements exist (then every valid element is inside).  hist: kNW*256 uint32 of LDS, misc: >= 4 ints.
-template <class KeyF>
+template <int NT = kNT, class KeyF>
 __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_t *hist, int *misc, uint32_t &T,
                                              int &need_eq, bool &all) {
+  constexpr int kNT = NT, kNW = NT / 64;
+  static_assert(NT >= 256 && NT % 64 == 0, "radix_select: the 256 bins are summed by the first 256 threads");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   __syncthreads();
   if (tid == 0) misc[2] = 0;
@@ -140,9 +145,10 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
 // half that holds the sorted order.  (The two halves are addressed through one base pointer and an integer
 // offset: selecting between two LDS pointers makes hipcc 7.2 emit an illegal null-check on
 // src_shared_base.)  hist: kNW*256 uint32 of LDS; wsum: kNW ints.  V <= 65536.
-template <class DigitF>
+template <int NT = kNT, class DigitF>
 __device__ __forceinline__ int block_sort_digits(DigitF digit, int npass, uint16_t *perm, int stride, int V,
                                                  uint32_t *hist, int *wsum) {
+  constexpr int kNT = NT, kNW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nchunks = (V + 63) >> 6;
   const int cpw = (nchunks + kNW - 1) / kNW;
@@ -163,7 +169,7 @@ __device__ __forceinline__ int block_sort_digits(DigitF digit, int npass, uint16
     {
       const uint32_t a0 = hist[4 * tid], a1 = hist[4 * tid + 1], a2 = hist[4 * tid + 2], a3 = hist[4 * tid + 3];
       int total;
-      const int ex = block_excl_scan((int)(a0 + a1 + a2 + a3), wsum, total);
+      const int ex = block_excl_scan<NT>((int)(a0 + a1 + a2 + a3), wsum, total);
       hist[4 * tid] = (uint32_t)ex;
       hist[4 * tid + 1] = (uint32_t)ex + a0;
       hist[4 * tid + 2] = (uint32_t)ex + a0 + a1;

@@ -46,12 +46,16 @@ static const int kDecMaxClasses = 256;
 // per-NMS-wave LDS: one 64-candidate tile + the kept list of the class being processed
 __host__ __device__ static inline size_t dec_wave_bytes(int Rpc4) { return (size_t)(64 + Rpc4) * 24; }
 
-__host__ __device__ static inline size_t dec_lds_bytes(int Vcap, int Rpc4, int nms_waves) {
-  return (size_t)Vcap * (4 + 4 + 2 + 2 + 2) + (size_t)kNW * 256 * 4 + 64 * 4 + (size_t)3 * (kDecMaxClasses + 4) * 4 +
+__host__ __device__ static inline size_t dec_lds_bytes(int Vcap, int Rpc4, int nms_waves, int nt) {
+  return (size_t)Vcap * (4 + 4 + 2 + 2 + 2) + (size_t)(nt / 64) * 256 * 4 + 64 * 4 + (size_t)3 * (kDecMaxClasses + 4) * 4 +
          (size_t)nms_waves * dec_wave_bytes(Rpc4);
 }
 
-__global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
+// NT = 1024: lowest latency; NT = 256: the small-footprint schedule of the stage pipeline (see proposal.hip).
+template <int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
+void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
+  constexpr int kNT = NT, kNW = NT / 64;
   // One workgroup per image: latency bound.  When the stage pipeline runs it beside the chip-filling crop kernel, the
   // crop's waves on this CU must not take its issue slots (they cost the crop 1/16 of its CUs, this kernel 40 %).
   __builtin_amdgcn_s_setprio(3);
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     }
   }
   int V;
-  int pos = block_excl_scan(cnt, wsum, V);
+  int pos = block_excl_scan<NT>(cnt, wsum, V);
   if (cnt) {
     int r = e0 / L;
     int l = e0 - r * L;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
   // ---- B. order by (class asc, score desc, roi asc) -----------------------------------------------------
   int soff = 0;  // offset of the sorted order inside perm
   if (V <= kNT) {
-    // rank by counting, all 1024 threads: `parts` threads share one candidate, each scanning a slice of the others
+    // rank by counting, all NT threads: `parts` threads share one candidate, each scanning a slice of the others
     // (LDS broadcast reads), partial ranks summed in LDS.  V is a few hundred: one thread per candidate left 3/4 of the
     // workgroup idle for V dependent LDS round trips.
     const int Vp = (V + 63) & ~63;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
     __syncthreads();
   } else {
     for (int i = tid; i < V; i += kNT) perm[i] = (uint16_t)i;  // (published by the sort's first barrier)
-    soff = block_sort_digits(
+    soff = block_sort_digits<NT>(
         [&](int slot, int pass) -> uint32_t { return pass < 4 ? (key[slot] >> (8 * pass)) : (pk[slot] >> 24); }, 5, perm,
         Vcap, V, hist, wsum);
   }
@@ -421,17 +425,19 @@ __global__ __launch_bounds__(1024) void decoder_kernel(DecoderParams p, int Vcap
 // generic sort -> NMS -> merge pipeline.
 int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
                    int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
-                   float *out_scores, int *out_valid, hipStream_t stream, bool *handled) {
+                   float *out_scores, int *out_valid, hipStream_t stream, bool small_footprint, bool *handled) {
   *handled = false;
+  if (const char *e = getenv("FRCNN_DECODER_THREADS")) small_footprint = atoi(e) == 256;  // diagnostic override
+  const int nt = small_footprint ? 256 : 1024;
   if (L > kDecMaxClasses || R >= (1 << 24) || R <= 0 || max_total <= 0) return FRCNN_OK;
   const long long rl = (long long)R * L;
   if (rl > 65535) return FRCNN_OK;
   const int Vcap = (int)((rl + 7) & ~7ll);
   const int Rpc = max_total < R ? max_total : R;
   const int Rpc4 = (Rpc + 3) & ~3;
-  int nms_waves = 8;
-  while (nms_waves > 1 && dec_lds_bytes(Vcap, Rpc4, nms_waves) > 160 * 1024) nms_waves >>= 1;
-  const size_t lds = dec_lds_bytes(Vcap, Rpc4, nms_waves);
+  int nms_waves = small_footprint ? 4 : 8;
+  while (nms_waves > 1 && dec_lds_bytes(Vcap, Rpc4, nms_waves, nt) > 160 * 1024) nms_waves >>= 1;
+  const size_t lds = dec_lds_bytes(Vcap, Rpc4, nms_waves, nt);
   if (lds > 160 * 1024) return FRCNN_OK;
   DecoderParams p;
   p.rois = rois;
@@ -451,14 +457,14 @@ int launch_decoder(const float *rois, const float *deltas, const float *probs, c
   p.out_labels = out_labels;
   p.out_scores = out_scores;
   p.out_valid = out_valid;
-  auto kern = decoder_kernel;
+  auto kern = small_footprint ? decoder_kernel<256> : decoder_kernel<1024>;
   if (lds > 48 * 1024) {
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "decoder: hipFuncSetAttribute");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kNT), lds, stream, p, Vcap, Rpc4, nms_waves);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(nt), lds, stream, p, Vcap, Rpc4, nms_waves);
   *handled = true;
   return check_launch("decoder (fused kernel)");
 }

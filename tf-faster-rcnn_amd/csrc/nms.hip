@@ -354,7 +354,7 @@ static int run_combined(const ScoreSource &score, const BoxSource &box, int B, i
 // proposal.hip
 int launch_proposal(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
                     int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
-                    int *out_valid, hipStream_t stream, bool *handled);
+                    int *out_valid, hipStream_t stream, bool small_footprint, bool *handled);
 
 // nms_bitmask.hip
 bool roi_bbox_bitmask_applies(int B, int K, int R_nms);
@@ -366,7 +366,7 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
 // decoder.hip
 int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
                    int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
-                   float *out_scores, int *out_valid, hipStream_t stream, bool *handled);
+                   float *out_scores, int *out_valid, hipStream_t stream, bool small_footprint, bool *handled);
 
 }  // namespace frcnn
 
@@ -446,7 +446,7 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
         return launch_roi_bbox_bitmask(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
                                        out_scores, out_valid, workspace, workspace_bytes, (hipStream_t)stream);
       int rc = launch_proposal(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
-                               out_scores, out_valid, (hipStream_t)stream, &handled);
+                               out_scores, out_valid, (hipStream_t)stream, false, &handled);
       if (rc || handled) return rc;
     }
   }
@@ -500,7 +500,7 @@ int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
     if (!(force && force[0] == '1')) {
       bool handled = false;
       int rc = launch_decoder(rois, deltas, probs, variances, B, R, L, max_total, score_threshold, iou_threshold,
-                              out_boxes, out_labels, out_scores, out_valid, (hipStream_t)stream, &handled);
+                              out_boxes, out_labels, out_scores, out_valid, (hipStream_t)stream, false, &handled);
       if (rc || handled) return rc;
     }
   }

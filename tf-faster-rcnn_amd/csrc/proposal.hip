@@ -35,15 +35,21 @@ struct ProposalParams {
   int *out_valid;     // (B) or NULL
 };
 
-template <int CH>
+template <int CH, int NT>
 static inline size_t proposal_lds_bytes(int Rc, int S) {
-  return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)kNW * 256 * 4 + 64 * 4;
+  return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)(NT / 64) * 256 * 4 + 64 * 4;
 }
 
 // cache_keys: the image's N sort keys are held in LDS (after the other arrays) so that the radix-select
 // passes and the compaction read LDS instead of re-reading the scores through L2.
-template <int CH>
-__global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
+// NT = 1024: the whole CU works on the image (lowest latency; what the layers use when called one after the other).
+// NT = 256 ("small footprint", frcnn_roi_bbox's FRCNN_SCHED_SMALL flag): four waves and at most 128 VGPRs, the shape of a
+// crop_and_resize workgroup, so that the workgroup becomes resident beside the crop kernel's as soon as one of those
+// retires instead of waiting for a crop launch's tail (tools/coresidency_probe.hip) -- the stage pipeline's choice.
+template <int CH, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
+void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
+  constexpr int kNT = NT, kNW = NT / 64;
   // One workgroup per image: latency bound.  When the stage pipeline runs it beside the chip-filling crop kernel, the
   // crop's waves on this CU must not take its issue slots (they cost the crop 1/16 of its CUs, this kernel 40 %).
   __builtin_amdgcn_s_setprio(3);
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc
     uint32_t T2;
     int eq2;
     bool all;
-    radix_select(keyf, N, consumed + s_now, hist, misc, T2, eq2, all);
+    radix_select<NT>(keyf, N, consumed + s_now, hist, misc, T2, eq2, all);
     FRCNN_STAMP(2);
     if (all) {  // cannot happen while K <= N; kept for safety
       T2 = 0xFFFFFFFFu;
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc
       e2 += (k == T2);
     }
     int tot;
-    const int base1 = block_excl_scan(e1, wsum, tot);
-    const int base2 = block_excl_scan(e2, wsum, tot);
+    const int base1 = block_excl_scan<NT>(e1, wsum, tot);
+    const int base2 = block_excl_scan<NT>(e2, wsum, tot);
     int cnt = 0;
     {
       int r1 = base1, r2 = base2;
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc
       }
     }
     int V;
-    int pos = block_excl_scan(cnt, wsum, V);
+    int pos = block_excl_scan<NT>(cnt, wsum, V);
     {
       int r1 = base1, r2 = base2;
       for (int i = i0; i < i1; ++i) {
@@ -164,14 +170,14 @@ __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc
     for (int i = 0; i < kNW; ++i) kmin = (uint32_t)wsum[i] < kmin ? (uint32_t)wsum[i] : kmin;
     const uint32_t diff = kmin ^ T2;
     const int npass = (V > 1 && diff) ? (32 - __builtin_clz(diff) + 7) / 8 : 1;
-    const int soff = block_sort_digits([&](int slot, int pass) -> uint32_t { return keys[slot] >> (8 * pass); }, npass, permA, S,
+    const int soff = block_sort_digits<NT>([&](int slot, int pass) -> uint32_t { return keys[slot] >> (8 * pass); }, npass, permA, S,
                                        V, hist, wsum);
     const uint16_t *perm = permA + soff;
     FRCNN_STAMP(4);
     // ---- 4. greedy NMS over the slice ------------------------------------------------------------------
     for (int cbase = 0; cbase < V && nk < R; cbase += CH) {
       const int nc = (V - cbase < CH) ? (V - cbase) : CH;
-      nk = nms_chunk<1024, CH>(L, nc, nk, R, p.iou, [&](int j, float4 &box, int &ei, bool &bad) {
+      nk = nms_chunk<NT, CH>(L, nc, nk, R, p.iou, [&](int j, float4 &box, int &ei, bool &bad) {
         ei = (int)orig[perm[cbase + j]];
         box = box_of(ei);
         bad = !(scores[ei] > p.score_thr);
@@ -203,20 +209,20 @@ __global__ __launch_bounds__(1024) void proposal_kernel(ProposalParams p, int Rc
   FRCNN_STAMP(9);
 }
 
-template <int CH>
+template <int CH, int NT>
 static int launch_proposal_t(ProposalParams &p, int B, int Rc, int S, hipStream_t stream, bool *handled) {
-  size_t lds = proposal_lds_bytes<CH>(Rc, S);
+  size_t lds = proposal_lds_bytes<CH, NT>(Rc, S);
   if (lds > 160 * 1024) return FRCNN_OK;  // does not fit: the caller takes the unfused path
   const int cache_keys = (lds + (size_t)p.N * 4 <= 160 * 1024) ? 1 : 0;
   if (cache_keys) lds += (size_t)p.N * 4;
-  auto kern = proposal_kernel<CH>;
+  auto kern = proposal_kernel<CH, NT>;
   if (lds > 48 * 1024) {
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                        "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kNT), lds, stream, p, Rc, S, cache_keys);
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NT), lds, stream, p, Rc, S, cache_keys);
   *handled = true;
   return check_launch("roi_bbox (fused proposal kernel)");
 }
@@ -225,7 +231,7 @@ static int launch_proposal_t(ProposalParams &p, int B, int Rc, int S, hipStream_
 // unfused sort -> NMS path.
 int launch_proposal(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
                     int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
-                    int *out_valid, hipStream_t stream, bool *handled) {
+                    int *out_valid, hipStream_t stream, bool small_footprint, bool *handled) {
   *handled = false;
   // R_out rows are written; at most R_nms = min(R_out, K) boxes can be kept.
   if (R_nms != R_out) return FRCNN_OK;  // zero rows beyond K candidates: leave to the generic path
@@ -255,9 +261,14 @@ int launch_proposal(const float *deltas, const float *scores, const float *ancho
   // chunk width: tuning knob (FRCNN_PROPOSAL_CHUNK = 64 | 128 | 256), default 128
   int ch = 128;
   if (const char *e = getenv("FRCNN_PROPOSAL_CHUNK")) ch = atoi(e);
-  if (ch == 64) return launch_proposal_t<64>(p, B, Rc, S, stream, handled);
-  if (ch == 256) return launch_proposal_t<256>(p, B, Rc, S, stream, handled);
-  return launch_proposal_t<128>(p, B, Rc, S, stream, handled);
+  if (const char *e = getenv("FRCNN_PROPOSAL_THREADS")) small_footprint = atoi(e) == 256;  // diagnostic override
+  if (small_footprint) {
+    if (ch == 64) return launch_proposal_t<64, 256>(p, B, Rc, S, stream, handled);
+    return launch_proposal_t<128, 256>(p, B, Rc, S, stream, handled);
+  }
+  if (ch == 64) return launch_proposal_t<64, 1024>(p, B, Rc, S, stream, handled);
+  if (ch == 256) return launch_proposal_t<256, 1024>(p, B, Rc, S, stream, handled);
+  return launch_proposal_t<128, 1024>(p, B, Rc, S, stream, handled);
 }
 
 }  // namespace frcnn
