@@ -116,7 +116,9 @@ def main() -> None:
     ap.add_argument("--mode", choices=("pipeline", "sequential"), default="pipeline",
                     help="pipeline: stages on three HIP streams, --depth batches in flight (tf_faster_rcnn_amd.pipeline); "
                          "sequential: the three layers one after the other on one stream")
-    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--crop-group", type=int, default=2,
+                    help="pipeline mode: consecutive batches that share one launch per stage (the *_multi entry points)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None,
                     help="GPU index for this rank (default LOCAL_RANK); lets a 1-GPU box rehearse the N-rank launch path")
@@ -170,12 +172,14 @@ def main() -> None:
         dets = decoder([rois, hd, hp])
         return pooled, dets
 
-    pipe = pkg.pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=args.depth)
+    group = args.crop_group
+    pipe = pkg.pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=args.depth, crop_group=group)
 
     def step_pipeline(i=None):
         # every step is a full pass (RoIBBox -> RoIPooling -> Decoder) over its batch; the stages of up to
         # --depth consecutive steps overlap on three streams.  The events bracket the crop kernel on ITS stream.
-        pipe.submit(deltas, scores, fm, (hd, hp), timing=None if (i is None or i % TIME_EVERY) else (ev0[i], ev1[i]))
+        # (with --crop-group g the first batch of every g carries the events of the group's one launch)
+        pipe.submit(deltas, scores, fm, (hd, hp), timing=None if (i is None or i % (TIME_EVERY * group)) else (ev0[i], ev1[i]))
 
     def barrier():
         pipe.synchronize()
@@ -207,7 +211,8 @@ def main() -> None:
         elapsed = float(t.item())
 
     crop_ms = float(np.mean([a.elapsed_time(b) for i, (a, b) in enumerate(zip(ev0, ev1))
-                             if args.mode == "sequential" or i % TIME_EVERY == 0])) if args.steps else float("nan")
+                             if args.mode == "sequential" or i % (TIME_EVERY * group) == 0])) if args.steps else float("nan")
+    launch_batches = group if args.mode == "pipeline" else 1  # batches one crop launch covers
     other = None
     if world == 1 and not args.no_other_schedule:  # the other schedule, same K steps, reported beside the headline (not part of `value`)
         other_elapsed = timed(step_sequential if args.mode == "pipeline" else step_pipeline, False)
@@ -218,7 +223,7 @@ def main() -> None:
     if rank == 0:
         images = cfg["B"] * world * args.steps
         value = images / elapsed
-        crop_bytes = crop_bytes_per_image(cfg) * cfg["B"]
+        crop_bytes = crop_bytes_per_image(cfg) * cfg["B"] * launch_batches
         achieved = crop_bytes / (crop_ms * 1e-3) / 1e9
         result = {
             "metric": "images/sec through RPN decode+NMS+RoIPool+class NMS (bs16, 500\u00b2); HBM GB/s",
@@ -237,11 +242,12 @@ def main() -> None:
             "config": {"workload": "BASELINE config 2: mobilenet_v2 RoI path, batch 16 per GPU, 500x500, 9216 anchors/img, "
                                    "pre_nms_topn 6000, post_nms 300, 7x7 crop_and_resize of 32x32x576, 21-label Decoder NMS",
                        "global_batch": cfg["B"] * world, "parallelism": f"dp{world} over images, no collectives",
-                       "schedule": (f"stage pipeline on 3 HIP streams, {args.depth} batches in flight" if args.mode == "pipeline"
+                       "schedule": (f"stage pipeline on 3 HIP streams, {args.depth} batches in flight, "
+                                    f"{group} consecutive batch(es) per launch of each stage" if args.mode == "pipeline"
                                     else "sequential on one stream")},
             "roofline": {"kernel": "crop_resize_kernel<4>", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic_bytes(), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
+                         "traffic": (lambda t: None if t is None else t * launch_batches)(pmc_traffic_bytes()), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
         }
         if other is not None:
             result["other_schedule"] = other

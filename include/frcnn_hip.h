@@ -108,6 +108,16 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
                    float *out_boxes, float *out_scores, int32_t *out_valid, void *workspace,
                    size_t workspace_bytes, frcnn_stream_t stream);
 
+/* frcnn_roi_bbox for `groups` (1..4) batches of one shape in ONE launch: deltas / scores / out_boxes are HOST arrays
+ * of `groups` device pointers.  No counterpart in the reference (which calls the layer once per batch,
+ * models/faster_rcnn.py:318); for serving loops that keep several batches in flight (RoIPathPipeline): the one
+ * workgroup per image of `groups` batches become resident together.  Same results as `groups` frcnn_roi_bbox calls;
+ * schedules without a grouped form are executed that way. */
+int frcnn_roi_bbox_multi(const float *const *deltas, const float *const *scores, const float *anchors,
+                         const float *variances, int groups, int B, int N, int K, int R,
+                         float iou_threshold, float *const *out_boxes, void *workspace,
+                         size_t workspace_bytes, frcnn_stream_t stream);
+
 /* tf.image.crop_and_resize(method="bilinear") as called at models/faster_rcnn.py:283-288.
  * image (B,H,W,C); boxes (n,4); box_ind (n) int32, or NULL meaning box i belongs to image
  * i / boxes_per_image (the RoIPooling layout, models/faster_rcnn.py:280-282).  out (n,ch,cw,C).
@@ -116,6 +126,17 @@ int frcnn_crop_and_resize(const float *image, int B, int H, int W, int C, const 
                           const int32_t *box_ind, int n, int boxes_per_image, int crop_h,
                           int crop_w, float extrapolation_value, float *out,
                           frcnn_stream_t stream);
+
+/* The same operation (models/faster_rcnn.py:283-288, RoIPooling layout: box_ind == NULL) for `groups` (1..4)
+ * independent batches of one shape in ONE launch: images / boxes / outs are HOST arrays of `groups` device pointers
+ * ((B,H,W,C), (n,4), (n,ch,cw,C) each).  The reference calls the layer once per batch; a serving loop that has
+ * several batches in flight (RoIPathPipeline) pays one launch tail and one inter-launch gap for all of them.
+ * Results are those of `groups` frcnn_crop_and_resize calls; shapes the grouped launch is not built for are
+ * executed that way. */
+int frcnn_crop_and_resize_multi(const float *const *images, const float *const *boxes,
+                                float *const *outs, int groups, int B, int H, int W, int C, int n,
+                                int boxes_per_image, int crop_h, int crop_w,
+                                float extrapolation_value, frcnn_stream_t stream);
 
 /* models/faster_rcnn.py:63-91 Decoder.call, fused: per-class variance scale + decode,
  * background-argmax masking, per-class NMS, cross-class top-T.  rois (B,R,4); deltas (B,R,L*4);
@@ -127,6 +148,15 @@ int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
                   float score_threshold, float iou_threshold, float *out_boxes,
                   float *out_labels, float *out_scores, int32_t *out_valid, void *workspace,
                   size_t workspace_bytes, frcnn_stream_t stream);
+
+/* frcnn_decoder for `groups` (1..4) batches of one shape in ONE launch (HOST arrays of device pointers), the
+ * Decoder-side companion of frcnn_roi_bbox_multi / frcnn_crop_and_resize_multi (models/faster_rcnn.py:361-365 is
+ * called once per batch in the reference).  Same results as `groups` frcnn_decoder calls. */
+int frcnn_decoder_multi(const float *const *rois, const float *const *deltas,
+                        const float *const *probs, const float *variances, int groups, int B, int R,
+                        int L, int max_total, float score_threshold, float iou_threshold,
+                        float *const *out_boxes, float *const *out_labels, float *const *out_scores,
+                        void *workspace, size_t workspace_bytes, frcnn_stream_t stream);
 
 /* ---- RPN target assignment ----------------------------------------------------------- */
 /* utils/train_utils.py:72-88 randomly_select_xyz_mask with the random integers supplied by the

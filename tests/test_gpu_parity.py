@@ -641,9 +641,11 @@ def test_config1_batch1_full_path(pkg):
 # ------------------------------------------------------------------------------------------------
 # stage pipeline over streams
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("depth,heads_callable", [(1, False), (3, False), (4, True)])
-def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable):
-    """Batches in flight on three streams give, per batch, exactly the sequential layers' (= the oracle's) results."""
+@pytest.mark.parametrize("depth,heads_callable,crop_group", [(1, False, 1), (3, False, 1), (4, True, 1), (4, False, 2),
+                                                             (3, True, 3), (4, True, 4)])
+def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop_group):
+    """Batches in flight on three streams give, per batch, exactly the sequential layers' (= the oracle's) results --
+    also when the crops of `crop_group` batches share one launch (7 batches: the last group is a partial one)."""
     from tf_faster_rcnn_amd import pipeline
 
     B, G, C, L = 4, 16, 32, 6
@@ -653,7 +655,7 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable):
     roi_bbox = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)
     roi_pool = pkg.faster_rcnn.RoIPooling(hp)
     decoder = pkg.faster_rcnn.Decoder(hp["variances"], L)
-    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=depth)
+    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=depth, crop_group=crop_group)
     batches = []
     for seed in range(7):
         deltas, scores = synth.rpn_outputs(seed, B, G)
@@ -682,6 +684,35 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable):
         for name, want in (("roi_bboxes", rois), ("roi_pooled", pooled), ("bboxes", boxes), ("labels", labels), ("scores", sc)):
             assert_bits(got[i][name], want, f"pipeline batch {i} {name} vs oracle")
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
+
+
+@pytest.mark.parametrize("groups,C,H", [(1, 32, 9), (2, 576, 12), (3, 20, 7), (4, 64, 5), (2, 6, 8)])
+def test_crop_and_resize_multi_matches_oracle(pkg, groups, C, H):
+    """frcnn_crop_and_resize_multi through the C ABI: `groups` (image, boxes, out) triples in one call, each bit-identical
+    to the oracle's roi_pooling of that triple (C % 4 != 0 takes the one-launch-per-triple route)."""
+    import ctypes
+
+    from tf_faster_rcnn_amd import _lib
+
+    rng = np.random.default_rng(100 + groups)
+    B, R, W = 3, 11, H + 2
+    fms = [rng.normal(0, 1, (B, H, W, C)).astype(np.float32) for _ in range(groups)]
+    rois = [rng.uniform(-0.1, 1.1, (B, R, 4)).astype(np.float32) for _ in range(groups)]
+    rois[0][0, 0] = 0.0  # a zero-padded RoI
+    d_fm, d_rois = [dev(a) for a in fms], [dev(a) for a in rois]
+    outs = [torch.full((B, R, 7, 7, C), float("nan"), dtype=torch.float32, device="cuda") for _ in range(groups)]
+    arr = ctypes.c_void_p * groups
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_rois]),
+                                                     arr(*[t.data_ptr() for t in outs]), groups, B, H, W, C, B * R, R, 7, 7,
+                                                     0.0, stream))
+    torch.cuda.synchronize()
+    for g in range(groups):
+        assert_bits(outs[g], oracle.roi_pooling(fms[g], rois[g], (7, 7)), f"crop multi triple {g} of {groups} C={C}")
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_rois]),
+                                                         arr(*[t.data_ptr() for t in outs]), 5, B, H, W, C, B * R, R, 7, 7,
+                                                         0.0, stream))
 
 
 # ------------------------------------------------------------------------------------------------

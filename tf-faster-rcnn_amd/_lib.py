@@ -45,9 +45,12 @@ SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
     "frcnn_combined_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_roi_bbox_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "frcnn_roi_bbox": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_roi_bbox_multi": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _i, _f, _vp, _vp, _sz, _vp]),
     "frcnn_crop_and_resize": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "frcnn_crop_and_resize_multi": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "frcnn_decoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "frcnn_decoder": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "frcnn_decoder_multi": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "frcnn_rpn_targets_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_rpn_targets": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
@@ -122,6 +125,11 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr_table(tensors: Sequence[torch.Tensor]):
+    """Host array of device pointers (the `*_multi` entry points' pointer tables)."""
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
 def float4(values: Sequence[float]):

@@ -201,12 +201,21 @@ __global__ __launch_bounds__(256) void crop_resize_slice_kernel(
 // ROWS = false: one workgroup per box (all ch*cw output pixels); ROWS = true: one workgroup per (box, output row), i.e.
 // cw pixels = 16 KB at 7 x 576 -- a single trip of 4 outputs per lane, seven times as many workgroups and a tighter
 // write front.  `units` = number of workgroups' worth of work (n or n*ch).
+// Up to kCropGroups independent (image, boxes, out) triples of one shape handled by ONE launch (frcnn_crop_and_resize_multi:
+// the stage pipeline crops two or more batches per launch, one launch tail and one inter-launch gap for all of them).
+static const int kCropGroups = 4;
+struct CropGroups {
+  const float *image[kCropGroups];
+  const float *boxes[kCropGroups];
+  float *out[kCropGroups];
+  int n_per_group;  // boxes per triple; 0 = a single triple (no group arithmetic)
+};
+
 template <int VEC, bool ROWS, int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void crop_resize_kernel(
-    const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
-    const int *__restrict__ box_ind, int units, int boxes_per_image, int ch, int cw, float extrap,
-    float *__restrict__ out) {
+    CropGroups gr, int B, int H, int W, int C,
+    const int *__restrict__ box_ind, int units, int boxes_per_image, int ch, int cw, float extrap) {
   typedef typename VecT<VEC>::type vec_t;
   __shared__ PixParam pp[256];
 
@@ -218,8 +227,24 @@ void crop_resize_kernel(
   const int q = units >> 3, r = units & 7;
   const int start = (grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q;
   const int unit = start + slot;
-  const int box = ROWS ? unit / ch : unit;
+  int box = ROWS ? unit / ch : unit;
   const int pbeg = ROWS ? (unit - box * ch) * cw : 0;  // first output pixel of this workgroup
+  // which triple (workgroup-uniform; selects instead of indexing the kernel-argument arrays dynamically)
+  const float *__restrict__ image = gr.image[0];
+  const float *__restrict__ boxes = gr.boxes[0];
+  float *__restrict__ out = gr.out[0];
+  if (gr.n_per_group > 0) {
+    const int g = box / gr.n_per_group;
+    box -= g * gr.n_per_group;
+#pragma unroll
+    for (int i = 1; i < kCropGroups; ++i) {
+      if (g == i) {
+        image = gr.image[i];
+        boxes = gr.boxes[i];
+        out = gr.out[i];
+      }
+    }
+  }
 
   const int bimg = box_ind ? box_ind[box] : (box / boxes_per_image);
   const bool img_ok = (bimg >= 0) && (bimg < B);
@@ -320,15 +345,60 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   const char *rows_env = getenv("FRCNN_CROP_ROWS");
   const bool rows_fit = (long long)n * crop_h < (1ll << 31);
   const bool use_rows = vec4 && rows_fit && (rows_env ? atoi(rows_env) != 0 : false);
+  CropGroups gr = {};
+  gr.image[0] = image;
+  gr.boxes[0] = boxes;
+  gr.out[0] = out;
+  gr.n_per_group = 0;
   if (use_rows) {
-    hipLaunchKernelGGL((crop_resize_kernel<4, true, 6>), dim3((unsigned)(n * crop_h)), block, 0, (hipStream_t)stream, image,
-                       B, H, W, C, boxes, box_ind, n * crop_h, boxes_per_image, crop_h, crop_w, extrapolation_value, out);
+    hipLaunchKernelGGL((crop_resize_kernel<4, true, 6>), dim3((unsigned)(n * crop_h)), block, 0, (hipStream_t)stream, gr,
+                       B, H, W, C, box_ind, n * crop_h, boxes_per_image, crop_h, crop_w, extrapolation_value);
   } else if (vec4) {
-    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, image,
-                       B, H, W, C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out);
+    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
+                       B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
   } else {
-    hipLaunchKernelGGL((crop_resize_kernel<1, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, image,
-                       B, H, W, C, boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out);
+    hipLaunchKernelGGL((crop_resize_kernel<1, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
+                       B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
   }
   return check_launch("crop_and_resize");
+}
+
+extern "C" int frcnn_crop_and_resize_multi(const float *const *images, const float *const *boxes, float *const *outs,
+                                           int groups, int B, int H, int W, int C, int n, int boxes_per_image, int crop_h,
+                                           int crop_w, float extrapolation_value, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(images && boxes && outs, "crop_and_resize_multi: null pointer table");
+  FRCNN_REQUIRE(groups >= 1 && groups <= kCropGroups, "crop_and_resize_multi: groups must be 1..%d (got %d)", kCropGroups, groups);
+  FRCNN_REQUIRE(boxes_per_image > 0, "crop_and_resize_multi: boxes_per_image must be positive");
+  FRCNN_REQUIRE(n >= 0, "crop_and_resize_multi: negative box count");
+  bool one_launch = groups > 1 && n > 0 && (C % 4 == 0) && (long long)n * groups < (1ll << 28) &&
+                    !((double)H * W * C * 4 > 4.0 * 1024 * 1024) && !getenv("FRCNN_CROP_SLICE") && !getenv("FRCNN_CROP_ROWS");
+  for (int g = 0; g < groups; ++g) {
+    FRCNN_REQUIRE(images[g] && boxes[g] && outs[g], "crop_and_resize_multi: null pointer in triple %d", g);
+    one_launch = one_launch && aligned_to(images[g], 16) && aligned_to(outs[g], 16);
+  }
+  if (!one_launch) {  // shapes the grouped launch is not built for: one launch per triple, same results
+    for (int g = 0; g < groups; ++g) {
+      const int rc = frcnn_crop_and_resize(images[g], B, H, W, C, boxes[g], nullptr, n, boxes_per_image, crop_h, crop_w,
+                                           extrapolation_value, outs[g], stream);
+      if (rc) return rc;
+    }
+    return FRCNN_OK;
+  }
+  FRCNN_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, "crop_and_resize_multi: image shape (%d,%d,%d,%d) must be positive", B, H, W, C);
+  FRCNN_REQUIRE(crop_h > 0 && crop_w > 0, "crop_and_resize_multi: crop size (%d,%d) must be positive", crop_h, crop_w);
+  FRCNN_REQUIRE((long long)H * W * C < (1ll << 30), "crop_and_resize_multi: one image must hold fewer than 2^30 floats");
+  FRCNN_REQUIRE(C < (1 << 20), "crop_and_resize_multi: depth must be below 2^20");
+  FRCNN_REQUIRE((long long)crop_h * crop_w < (1ll << 24), "crop_and_resize_multi: crop too large");
+  CropGroups gr = {};
+  for (int g = 0; g < kCropGroups; ++g) {
+    const int s = g < groups ? g : 0;
+    gr.image[g] = images[s];
+    gr.boxes[g] = boxes[s];
+    gr.out[g] = outs[s];
+  }
+  gr.n_per_group = n;
+  hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), dim3((unsigned)(n * groups)), dim3(256), 0,
+                     (hipStream_t)stream, gr, B, H, W, C, (const int *)nullptr, n * groups, boxes_per_image, crop_h, crop_w,
+                     extrapolation_value);
+  return check_launch("crop_and_resize_multi");
 }

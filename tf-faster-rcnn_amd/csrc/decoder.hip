@@ -27,18 +27,25 @@
 
 namespace frcnn {
 
-struct DecoderParams {
+// One batch's tensors; a launch covers up to kDecoderGroups batches of one shape (frcnn_decoder_multi).
+static const int kDecoderGroups = 4;
+struct DecoderIO {
   const float *rois;    // (B,R,4)
   const float *deltas;  // (B,R,L,4)
   const float *probs;   // (B,R,L)
+  float *out_boxes;     // (B,T,4)
+  float *out_labels;    // (B,T) or NULL
+  float *out_scores;    // (B,T) or NULL
+  int *out_valid;       // (B) or NULL
+};
+
+struct DecoderParams {
+  DecoderIO io[kDecoderGroups];
+  int images_per_group;  // B of one batch
   float v0, v1, v2, v3;
   int R, L, T, Rpc;     // Rpc = min(max_output_size_per_class, R)
   float score_thr;
   IouThr iou;
-  float *out_boxes;   // (B,T,4)
-  float *out_labels;  // (B,T) or NULL
-  float *out_scores;  // (B,T) or NULL
-  int *out_valid;     // (B) or NULL
 };
 
 static const int kDecMaxClasses = 256;
@@ -73,11 +80,20 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
   uint16_t *perm = reinterpret_cast<uint16_t *>(kcount + kDecMaxClasses + 4);  // [2*Vcap]
   uint16_t *klist = perm + 2 * Vcap;                          // [Vcap] kept slots; class c at klist[cstart[c] ..]
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int b = blockIdx.x;
+  DecoderIO io = p.io[0];
+  {  // which batch (workgroup-uniform selects)
+    const int g = b / p.images_per_group;
+    b -= g * p.images_per_group;
+#pragma unroll
+    for (int i = 1; i < kDecoderGroups; ++i)
+      if (g == i) io = p.io[i];
+  }
   const int R = p.R, L = p.L, T = p.T;
-  const float *probs = p.probs + (long long)b * R * L;
-  const float4 *rois = reinterpret_cast<const float4 *>(p.rois) + (long long)b * R;
-  const float4 *deltas = reinterpret_cast<const float4 *>(p.deltas) + (long long)b * R * L;
+  const float *probs = io.probs + (long long)b * R * L;
+  const float4 *rois = reinterpret_cast<const float4 *>(io.rois) + (long long)b * R;
+  const float4 *deltas = reinterpret_cast<const float4 *>(io.deltas) + (long long)b * R * L;
 
   auto box_of = [&](int r, int cls) -> float4 {
     return decode_box(rois[r], scale_deltas(deltas[(long long)r * L + cls], p.v0, p.v1, p.v2, p.v3));
@@ -407,28 +423,30 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
       o.y = clip01(o.y);
       o.z = clip01(o.z);
       o.w = clip01(o.w);
-      *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * T + rank) * 4) = o;
-      if (p.out_scores) p.out_scores[(long long)b * T + rank] = probs[(long long)r * L + cls];
-      if (p.out_labels) p.out_labels[(long long)b * T + rank] = (float)cls;
+      *reinterpret_cast<float4 *>(io.out_boxes + ((long long)b * T + rank) * 4) = o;
+      if (io.out_scores) io.out_scores[(long long)b * T + rank] = probs[(long long)r * L + cls];
+      if (io.out_labels) io.out_labels[(long long)b * T + rank] = (float)cls;
     }
   }
   for (int r = nvalid + tid; r < T; r += kNT) {
-    *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * T + r) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.out_scores) p.out_scores[(long long)b * T + r] = 0.0f;
-    if (p.out_labels) p.out_labels[(long long)b * T + r] = 0.0f;
+    *reinterpret_cast<float4 *>(io.out_boxes + ((long long)b * T + r) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (io.out_scores) io.out_scores[(long long)b * T + r] = 0.0f;
+    if (io.out_labels) io.out_labels[(long long)b * T + r] = 0.0f;
   }
-  if (tid == 0 && p.out_valid) p.out_valid[b] = nvalid;
+  if (tid == 0 && io.out_valid) io.out_valid[b] = nvalid;
   FRCNN_STAMP(25);
 }
 
 // *handled stays false when the fused kernel cannot hold the problem in LDS; the caller then takes the
 // generic sort -> NMS -> merge pipeline.
-int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
-                   int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
-                   float *out_scores, int *out_valid, hipStream_t stream, bool small_footprint, bool *handled) {
+int launch_decoder(const float *const *rois, const float *const *deltas, const float *const *probs, int groups,
+                   const float *variances, int B, int R, int L, int max_total, float score_thr, float iou_thr,
+                   float *const *out_boxes, float *const *out_labels, float *const *out_scores, int *const *out_valid,
+                   hipStream_t stream, bool small_footprint, bool *handled) {
   *handled = false;
   if (const char *e = getenv("FRCNN_DECODER_THREADS")) small_footprint = atoi(e) == 256;  // diagnostic override
   const int nt = small_footprint ? 256 : 1024;
+  if (groups < 1 || groups > kDecoderGroups) return FRCNN_OK;
   if (L > kDecMaxClasses || R >= (1 << 24) || R <= 0 || max_total <= 0) return FRCNN_OK;
   const long long rl = (long long)R * L;
   if (rl > 65535) return FRCNN_OK;
@@ -440,9 +458,17 @@ int launch_decoder(const float *rois, const float *deltas, const float *probs, c
   const size_t lds = dec_lds_bytes(Vcap, Rpc4, nms_waves, nt);
   if (lds > 160 * 1024) return FRCNN_OK;
   DecoderParams p;
-  p.rois = rois;
-  p.deltas = deltas;
-  p.probs = probs;
+  for (int g = 0; g < kDecoderGroups; ++g) {
+    const int s = g < groups ? g : 0;
+    p.io[g].rois = rois[s];
+    p.io[g].deltas = deltas[s];
+    p.io[g].probs = probs[s];
+    p.io[g].out_boxes = out_boxes[s];
+    p.io[g].out_labels = out_labels ? out_labels[s] : nullptr;
+    p.io[g].out_scores = out_scores ? out_scores[s] : nullptr;
+    p.io[g].out_valid = out_valid ? out_valid[s] : nullptr;
+  }
+  p.images_per_group = B;
   p.v0 = variances[0];
   p.v1 = variances[1];
   p.v2 = variances[2];
@@ -453,10 +479,6 @@ int launch_decoder(const float *rois, const float *deltas, const float *probs, c
   p.Rpc = Rpc;
   p.score_thr = score_thr;
   p.iou = make_iou_thr(iou_thr);
-  p.out_boxes = out_boxes;
-  p.out_labels = out_labels;
-  p.out_scores = out_scores;
-  p.out_valid = out_valid;
   auto kern = small_footprint ? decoder_kernel<256> : decoder_kernel<1024>;
   if (lds > 48 * 1024) {
     int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -464,7 +486,7 @@ int launch_decoder(const float *rois, const float *deltas, const float *probs, c
                        "decoder: hipFuncSetAttribute");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(nt), lds, stream, p, Vcap, Rpc4, nms_waves);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * groups)), dim3(nt), lds, stream, p, Vcap, Rpc4, nms_waves);
   *handled = true;
   return check_launch("decoder (fused kernel)");
 }

@@ -352,9 +352,9 @@ static int run_combined(const ScoreSource &score, const BoxSource &box, int B, i
 }
 
 // proposal.hip
-int launch_proposal(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
-                    int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
-                    int *out_valid, hipStream_t stream, bool small_footprint, bool *handled);
+int launch_proposal(const float *const *deltas, const float *const *scores, int groups, const float *anchors,
+                    const float *variances, int B, int N, int K, int R_out, int R_nms, float iou_thr, float *const *out_boxes,
+                    float *const *out_scores, int *const *out_valid, hipStream_t stream, bool small_footprint, bool *handled);
 
 // nms_bitmask.hip
 bool roi_bbox_bitmask_applies(int B, int K, int R_nms);
@@ -364,9 +364,10 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
                             int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 // decoder.hip
-int launch_decoder(const float *rois, const float *deltas, const float *probs, const float *variances, int B, int R,
-                   int L, int max_total, float score_thr, float iou_thr, float *out_boxes, float *out_labels,
-                   float *out_scores, int *out_valid, hipStream_t stream, bool small_footprint, bool *handled);
+int launch_decoder(const float *const *rois, const float *const *deltas, const float *const *probs, int groups,
+                   const float *variances, int B, int R, int L, int max_total, float score_thr, float iou_thr,
+                   float *const *out_boxes, float *const *out_labels, float *const *out_scores, int *const *out_valid,
+                   hipStream_t stream, bool small_footprint, bool *handled);
 
 }  // namespace frcnn
 
@@ -445,8 +446,8 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
       if (roi_bbox_bitmask_applies(B, K, Rn))
         return launch_roi_bbox_bitmask(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
                                        out_scores, out_valid, workspace, workspace_bytes, (hipStream_t)stream);
-      int rc = launch_proposal(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
-                               out_scores, out_valid, (hipStream_t)stream, false, &handled);
+      int rc = launch_proposal(&deltas, &scores, 1, anchors, variances, B, N, K, R, Rn, iou_threshold, &out_boxes,
+                               &out_scores, &out_valid, (hipStream_t)stream, false, &handled);
       if (rc || handled) return rc;
     }
   }
@@ -477,6 +478,37 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
                       nullptr, out_valid, workspace, workspace_bytes, (hipStream_t)stream, "roi_bbox");
 }
 
+int frcnn_roi_bbox_multi(const float *const *deltas, const float *const *scores, const float *anchors,
+                         const float *variances, int groups, int B, int N, int K, int R, float iou_threshold,
+                         float *const *out_boxes, void *workspace, size_t workspace_bytes, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(deltas && scores && out_boxes, "roi_bbox_multi: null pointer table");
+  FRCNN_REQUIRE(groups >= 1 && groups <= 4, "roi_bbox_multi: groups must be 1..4 (got %d)", groups);
+  FRCNN_REQUIRE(anchors && variances, "roi_bbox_multi: null pointer");
+  FRCNN_REQUIRE(B >= 0 && N > 0 && K > 0 && R >= 0, "roi_bbox_multi: bad shape B=%d N=%d K=%d R=%d", B, N, K, R);
+  FRCNN_REQUIRE(K <= N, "roi_bbox_multi: input must have at least k columns (pre_nms_topn=%d, anchors=%d)", K, N);
+  bool ok = aligned_to(anchors, 16);
+  for (int g = 0; g < groups; ++g) {
+    FRCNN_REQUIRE(deltas[g] && scores[g] && out_boxes[g], "roi_bbox_multi: null pointer in batch %d", g);
+    ok = ok && aligned_to(deltas[g], 16) && aligned_to(out_boxes[g], 16);
+  }
+  FRCNN_REQUIRE(ok, "roi_bbox_multi: box pointers must be 16-byte aligned");
+  if (B == 0) return FRCNN_OK;
+  const int Rn = R < K ? R : K;
+  const char *force = getenv("FRCNN_ROI_BBOX_UNFUSED");
+  if (groups > 1 && !(force && force[0] == '1') && !roi_bbox_bitmask_applies(B, K, Rn)) {
+    bool handled = false;
+    int rc = launch_proposal(deltas, scores, groups, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes, nullptr,
+                             nullptr, (hipStream_t)stream, false, &handled);
+    if (rc || handled) return rc;
+  }
+  for (int g = 0; g < groups; ++g) {  // schedules without a grouped form: one call per batch (stream-ordered workspace reuse)
+    int rc = frcnn_roi_bbox(deltas[g], scores[g], anchors, variances, B, N, K, R, iou_threshold, out_boxes[g], nullptr,
+                            nullptr, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return FRCNN_OK;
+}
+
 size_t frcnn_decoder_workspace_bytes(int B, int R, int L, int max_total) {
   if (B < 0 || R < 0 || L <= 0) return 0;
   const int Rr = max_total < R ? max_total : R;
@@ -499,8 +531,8 @@ int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
     const char *force = getenv("FRCNN_DECODER_UNFUSED");
     if (!(force && force[0] == '1')) {
       bool handled = false;
-      int rc = launch_decoder(rois, deltas, probs, variances, B, R, L, max_total, score_threshold, iou_threshold,
-                              out_boxes, out_labels, out_scores, out_valid, (hipStream_t)stream, false, &handled);
+      int rc = launch_decoder(&rois, &deltas, &probs, 1, variances, B, R, L, max_total, score_threshold, iou_threshold,
+                              &out_boxes, &out_labels, &out_scores, &out_valid, (hipStream_t)stream, false, &handled);
       if (rc || handled) return rc;
     }
   }
@@ -525,6 +557,37 @@ int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
   return run_combined(ss, bs, B, R, L, max_total, max_total, iou_threshold, true, score_threshold, 0, 1,
                       out_boxes, out_scores, out_labels, out_valid, workspace, workspace_bytes,
                       (hipStream_t)stream, "decoder");
+}
+
+
+int frcnn_decoder_multi(const float *const *rois, const float *const *deltas, const float *const *probs,
+                        const float *variances, int groups, int B, int R, int L, int max_total, float score_threshold,
+                        float iou_threshold, float *const *out_boxes, float *const *out_labels,
+                        float *const *out_scores, void *workspace, size_t workspace_bytes, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(rois && deltas && probs && out_boxes && out_labels && out_scores, "decoder_multi: null pointer table");
+  FRCNN_REQUIRE(groups >= 1 && groups <= 4, "decoder_multi: groups must be 1..4 (got %d)", groups);
+  FRCNN_REQUIRE(variances, "decoder_multi: null pointer");
+  FRCNN_REQUIRE(B >= 0 && R >= 0 && L > 0 && max_total >= 0, "decoder_multi: bad shape B=%d R=%d L=%d T=%d", B, R, L, max_total);
+  bool ok = true;
+  for (int g = 0; g < groups; ++g) {
+    FRCNN_REQUIRE(rois[g] && deltas[g] && probs[g] && out_boxes[g], "decoder_multi: null pointer in batch %d", g);
+    ok = ok && aligned_to(rois[g], 16) && aligned_to(deltas[g], 16) && aligned_to(out_boxes[g], 16);
+  }
+  FRCNN_REQUIRE(ok, "decoder_multi: box pointers must be 16-byte aligned");
+  if (B == 0) return FRCNN_OK;
+  const char *force = getenv("FRCNN_DECODER_UNFUSED");
+  if (groups > 1 && !(force && force[0] == '1')) {
+    bool handled = false;
+    int rc = launch_decoder(rois, deltas, probs, groups, variances, B, R, L, max_total, score_threshold, iou_threshold,
+                            out_boxes, out_labels, out_scores, nullptr, (hipStream_t)stream, false, &handled);
+    if (rc || handled) return rc;
+  }
+  for (int g = 0; g < groups; ++g) {  // no grouped form for this shape: one call per batch
+    int rc = frcnn_decoder(rois[g], deltas[g], probs[g], variances, B, R, L, max_total, score_threshold, iou_threshold,
+                           out_boxes[g], out_labels[g], out_scores[g], nullptr, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+  }
+  return FRCNN_OK;
 }
 
 }  // extern "C"

@@ -22,17 +22,25 @@
 
 namespace frcnn {
 
+// One batch's tensors.  A launch covers up to kProposalGroups batches of one shape (frcnn_roi_bbox_multi: the stage
+// pipeline's proposals for the batches whose crops share a launch).
+static const int kProposalGroups = 4;
+struct ProposalIO {
+  const float *deltas;  // (B,N,4)
+  const float *scores;  // (B,N)
+  float *out_boxes;     // (B,R,4)
+  float *out_scores;    // (B,R) or NULL
+  int *out_valid;       // (B) or NULL
+};
+
 struct ProposalParams {
-  const float *deltas;   // (B,N,4)
-  const float *scores;   // (B,N)
+  ProposalIO io[kProposalGroups];
+  int images_per_group;  // B of one batch; workgroup blockIdx.x works on image blockIdx.x % B of batch blockIdx.x / B
   const float *anchors;  // (N,4)
   float v0, v1, v2, v3;
   int N, K, R;
   IouThr iou;
   float score_thr;  // -inf: combined_non_max_suppression's default, strict '>'
-  float *out_boxes;   // (B,R,4)
-  float *out_scores;  // (B,R) or NULL
-  int *out_valid;     // (B) or NULL
 };
 
 template <int CH, int NT>
@@ -65,10 +73,19 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
   // permB = permA + S                                         // [S] (ping-pong half)
   uint32_t *kcache = reinterpret_cast<uint32_t *>(permA + 2 * S);  // [N] when cache_keys
 
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  ProposalIO io = p.io[0];
+  {  // which batch (workgroup-uniform selects: no dynamic indexing of the kernel arguments)
+    const int g = b / p.images_per_group;
+    b -= g * p.images_per_group;
+#pragma unroll
+    for (int i = 1; i < kProposalGroups; ++i)
+      if (g == i) io = p.io[i];
+  }
   const int N = p.N, K = p.K, R = p.R;
-  const float *scores = p.scores + (long long)b * N;
-  const float4 *deltas = reinterpret_cast<const float4 *>(p.deltas) + (long long)b * N;
+  const float *scores = io.scores + (long long)b * N;
+  const float4 *deltas = reinterpret_cast<const float4 *>(io.deltas) + (long long)b * N;
   const float4 *anchors = reinterpret_cast<const float4 *>(p.anchors);
 
   FRCNN_STAMP(0);
@@ -202,10 +219,10 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
       o.w = clip01(o.w);
       sc = scores[ei];
     }
-    *reinterpret_cast<float4 *>(p.out_boxes + ((long long)b * R + r) * 4) = o;
-    if (p.out_scores) p.out_scores[(long long)b * R + r] = sc;
+    *reinterpret_cast<float4 *>(io.out_boxes + ((long long)b * R + r) * 4) = o;
+    if (io.out_scores) io.out_scores[(long long)b * R + r] = sc;
   }
-  if (tid == 0 && p.out_valid) p.out_valid[b] = nk;
+  if (tid == 0 && io.out_valid) io.out_valid[b] = nk;
   FRCNN_STAMP(9);
 }
 
@@ -229,13 +246,14 @@ static int launch_proposal_t(ProposalParams &p, int B, int Rc, int S, hipStream_
 
 // *handled stays false when the fused kernel cannot hold the problem in LDS; the caller then takes the
 // unfused sort -> NMS path.
-int launch_proposal(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
-                    int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
-                    int *out_valid, hipStream_t stream, bool small_footprint, bool *handled) {
+int launch_proposal(const float *const *deltas, const float *const *scores, int groups, const float *anchors,
+                    const float *variances, int B, int N, int K, int R_out, int R_nms, float iou_thr, float *const *out_boxes,
+                    float *const *out_scores, int *const *out_valid, hipStream_t stream, bool small_footprint, bool *handled) {
   *handled = false;
   // R_out rows are written; at most R_nms = min(R_out, K) boxes can be kept.
   if (R_nms != R_out) return FRCNN_OK;  // zero rows beyond K candidates: leave to the generic path
   if (R_nms > kMaxKept) return FRCNN_OK;
+  if (groups < 1 || groups > kProposalGroups) return FRCNN_OK;
   int Rc = (R_nms + 7) & ~7;
   if (Rc < 8) Rc = 8;
   // slice: a few times the number of boxes wanted, in whole chunks, at most 4096
@@ -243,8 +261,16 @@ int launch_proposal(const float *deltas, const float *scores, const float *ancho
   if (S < 1024) S = 1024;
   if (S > 4096) S = 4096;
   ProposalParams p;
-  p.deltas = deltas;
-  p.scores = scores;
+  for (int g = 0; g < kProposalGroups; ++g) {
+    const int s = g < groups ? g : 0;
+    p.io[g].deltas = deltas[s];
+    p.io[g].scores = scores[s];
+    p.io[g].out_boxes = out_boxes[s];
+    p.io[g].out_scores = out_scores ? out_scores[s] : nullptr;
+    p.io[g].out_valid = out_valid ? out_valid[s] : nullptr;
+  }
+  p.images_per_group = B;
+  B *= groups;  // workgroups of the launch
   p.anchors = anchors;
   p.v0 = variances[0];
   p.v1 = variances[1];
@@ -255,9 +281,6 @@ int launch_proposal(const float *deltas, const float *scores, const float *ancho
   p.R = R_nms;
   p.iou = make_iou_thr(iou_thr);
   p.score_thr = -__builtin_huge_valf();
-  p.out_boxes = out_boxes;
-  p.out_scores = out_scores;
-  p.out_valid = out_valid;
   // chunk width: tuning knob (FRCNN_PROPOSAL_CHUNK = 64 | 128 | 256), default 128
   int ch = 128;
   if (const char *e = getenv("FRCNN_PROPOSAL_CHUNK")) ch = atoi(e);

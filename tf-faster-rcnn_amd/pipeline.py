@@ -24,6 +24,7 @@ Host cost per batch is three C-ABI calls and a handful of event operations: outp
 
 from __future__ import annotations
 
+import ctypes
 import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
@@ -38,13 +39,14 @@ Heads = Union[Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.T
 
 
 class _Slot:
-    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy")
+    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy", "pending")
 
     def __init__(self) -> None:
         self.rois = self.pooled = self.boxes = self.labels = self.scores = None
         self.done = _lib.HipEvent(_lib.hipEventDisableTiming)  # host-visible: keeps the system-scope release
         self.inputs: Any = None
         self.busy = False
+        self.pending: Any = None  # (fm, heads, timing) while the batch waits for its group's crop launch
 
 
 class RoIPathPipeline:
@@ -54,11 +56,21 @@ class RoIPathPipeline:
         roi_bbox, roi_pooling, decoder: the layers (same objects the sequential path uses).
         depth: batches in flight = ring slots.  ``submit`` blocks the host once ``depth`` batches are
             pending, so a slot's tensors stay valid until ``depth - 1`` further submissions.
+        crop_group: batches that share ONE launch per stage (``frcnn_roi_bbox_multi``, ``frcnn_crop_and_resize_multi``,
+            ``frcnn_decoder_multi``).  With ``crop_group > 1`` a batch is enqueued when its group is complete (or at
+            ``flush`` / ``result`` / ``synchronize``): one launch tail and one inter-launch gap of the crop kernel per
+            group instead of per batch, and the one-workgroup-per-image kernels of the whole group become resident in
+            the same crop tail -- at the price of up to ``crop_group - 1`` submissions of extra latency.
     """
 
-    def __init__(self, roi_bbox: RoIBBox, roi_pooling: RoIPooling, decoder: Decoder, depth: int = 4) -> None:
+    def __init__(self, roi_bbox: RoIBBox, roi_pooling: RoIPooling, decoder: Decoder, depth: int = 4,
+                 crop_group: int = 1) -> None:
         if depth < 1:
             raise ValueError("depth must be >= 1")
+        if not 1 <= crop_group <= 4 or crop_group > depth:
+            raise ValueError("crop_group must be 1..4 and at most depth")
+        self.crop_group = crop_group
+        self._pending: List[int] = []  # slot indices whose proposals are enqueued and whose crop + Decoder are not yet
         self.roi_bbox, self.roi_pooling, self.decoder = roi_bbox, roi_pooling, decoder
         self.device = roi_bbox.anchors.device
         if self.device.type != "cuda":
@@ -122,7 +134,8 @@ class RoIPathPipeline:
         a callable ``heads(pooled, rois) -> (pred_deltas, pred_label_probs)`` that is run on the pooling
         stage's stream right after the crop (the dense heads of the model).  ``timing`` = two events
         (``_lib.HipEvent`` created with timing enabled; ``record(stream_handle)``) recorded immediately before and after
-        the crop kernel on its stream.
+        the crop kernel on its stream (with ``crop_group > 1``: around the group's launch, taken from the first batch
+        of the group that carries them).
         """
         lib = _lib.lib()
         dev = self.device
@@ -133,59 +146,89 @@ class RoIPathPipeline:
         k = self._count % self.depth
         slot = self.slots[k]
         if slot.busy:
+            if slot.pending is not None:
+                self.flush()
             t_wait = time.perf_counter()
             slot.done.synchronize()  # back-pressure; also makes dropping the old inputs safe
             self.wait_seconds += time.perf_counter() - t_wait
-        B, H, W, C = fm.shape
-        N = self.roi_bbox.anchors.shape[0]
-        R, T, L = self._R, int(self.decoder.max_total_size), int(self.decoder.total_labels)
-        s_pool = self.s_pool
-        q_prop, q_pool, q_dec = self.s_prop.cuda_stream, self.s_pool.cuda_stream, self.s_dec.cuda_stream
-
         ev_in = self._ev_in[k]
         ev_in.record(torch.cuda.current_stream(dev).cuda_stream)  # inputs were produced on the caller's stream
-        ev_in.wait(q_prop)
+        slot.pending = (fm, heads, timing)
+        slot.inputs = (deltas, scores, fm)  # keep alive until the slot comes round again
+        slot.busy = True
+        self._pending.append(k)
+        ticket = self._count
+        self._count += 1
+        if len(self._pending) >= self.crop_group:
+            self.flush()
+        return ticket
+
+    def flush(self) -> None:
+        """Enqueue the three stages of every submitted batch that is still waiting for its group: ONE proposal launch,
+        ONE crop launch and ONE Decoder launch for all of them (the `*_multi` entry points)."""
+        if not self._pending:
+            return
+        lib = _lib.lib()
+        dev = self.device
+        ks, self._pending = self._pending, []
+        slots = [self.slots[k] for k in ks]
+        n = len(slots)
+        N = self.roi_bbox.anchors.shape[0]
+        R, T, L = self._R, int(self.decoder.max_total_size), int(self.decoder.total_labels)
+        q_prop, q_pool, q_dec = self.s_prop.cuda_stream, self.s_pool.cuda_stream, self.s_dec.cuda_stream
+        fm0 = slots[0].pending[0]
+        B, H, W, C = fm0.shape
+        ph, pw = self._pool
+        tab = _lib.ptr_table
+
+        for k in ks:
+            self._ev_in[k].wait(q_prop)
         if "prop" not in self._skip:
-          _lib.check(lib.frcnn_roi_bbox(deltas.data_ptr(), scores.data_ptr(), self.roi_bbox.anchors.data_ptr(),
-                                      self._var_prop, B, N, self._K, R, self._thr, slot.rois.data_ptr(), None, None,
-                                      self._ws_prop.data_ptr(), self._ws_prop.numel(), q_prop))
-        ev_rois = self._ev_rois[k]
+            _lib.check(lib.frcnn_roi_bbox_multi(tab([s.inputs[0] for s in slots]), tab([s.inputs[1] for s in slots]),
+                                                self.roi_bbox.anchors.data_ptr(), self._var_prop, n, B, N, self._K, R,
+                                                self._thr, tab([s.rois for s in slots]), self._ws_prop.data_ptr(),
+                                                self._ws_prop.numel(), q_prop))
+        ev_rois = self._ev_rois[ks[0]]
         ev_rois.record(q_prop)
 
         ev_rois.wait(q_pool)  # (ev_in is implied: the proposal stage waited for it)
+        timing = next((s.pending[2] for s in slots if s.pending[2] is not None), None)
         if timing is not None:
             timing[0].record(q_pool)
-        ph, pw = self._pool
         if "crop" not in self._skip:
-          _lib.check(lib.frcnn_crop_and_resize(fm.data_ptr(), B, H, W, C, slot.rois.data_ptr(), None, B * R, R, ph, pw,
-                                             0.0, slot.pooled.data_ptr(), q_pool))
+            _lib.check(lib.frcnn_crop_and_resize_multi(tab([s.pending[0] for s in slots]), tab([s.rois for s in slots]),
+                                                       tab([s.pooled for s in slots]), n, B, H, W, C, B * R, R, ph, pw, 0.0,
+                                                       q_pool))
         if timing is not None:
             timing[1].record(q_pool)
-        if callable(heads):
-            with torch.cuda.stream(s_pool):
-                pred_deltas, pred_probs = heads(slot.pooled, slot.rois)
-        else:
-            pred_deltas, pred_probs = heads
-        pred_deltas = _lib.device_tensor(pred_deltas, torch.float32, dev)
-        pred_probs = _lib.device_tensor(pred_probs, torch.float32, dev)
-        if pred_deltas.numel() != B * R * L * 4 or tuple(pred_probs.shape) != (B, R, L):
-            raise ValueError(f"head outputs {tuple(pred_deltas.shape)} / {tuple(pred_probs.shape)} do not match "
-                             f"({B}, {R}, {L}*4) / ({B}, {R}, {L})")
-        ev_heads = self._ev_heads[k]
+        outs = []
+        for s in slots:
+            fm, heads, _ = s.pending
+            if callable(heads):
+                with torch.cuda.stream(self.s_pool):
+                    pred_deltas, pred_probs = heads(s.pooled, s.rois)
+            else:
+                pred_deltas, pred_probs = heads
+            pred_deltas = _lib.device_tensor(pred_deltas, torch.float32, dev)
+            pred_probs = _lib.device_tensor(pred_probs, torch.float32, dev)
+            if pred_deltas.numel() != B * R * L * 4 or tuple(pred_probs.shape) != (B, R, L):
+                raise ValueError(f"head outputs {tuple(pred_deltas.shape)} / {tuple(pred_probs.shape)} do not match "
+                                 f"({B}, {R}, {L}*4) / ({B}, {R}, {L})")
+            outs.append((pred_deltas, pred_probs))
+        ev_heads = self._ev_heads[ks[0]]
         ev_heads.record(q_pool)
 
         ev_heads.wait(q_dec)
         if "dec" not in self._skip:
-          _lib.check(lib.frcnn_decoder(slot.rois.data_ptr(), pred_deltas.data_ptr(), pred_probs.data_ptr(), self._var_dec,
-                                     B, R, L, T, float(self.decoder.score_threshold), 0.5, slot.boxes.data_ptr(),
-                                     slot.labels.data_ptr(), slot.scores.data_ptr(), None, self._ws_dec.data_ptr(),
-                                     self._ws_dec.numel(), q_dec))
-        slot.done.record(q_dec)
-        slot.inputs = (deltas, scores, fm, pred_deltas, pred_probs)  # keep alive until the slot comes round again
-        slot.busy = True
-        ticket = self._count
-        self._count += 1
-        return ticket
+            _lib.check(lib.frcnn_decoder_multi(tab([s.rois for s in slots]), tab([o[0] for o in outs]), tab([o[1] for o in outs]),
+                                               self._var_dec, n, B, R, L, T, float(self.decoder.score_threshold), 0.5,
+                                               tab([s.boxes for s in slots]), tab([s.labels for s in slots]),
+                                               tab([s.scores for s in slots]), self._ws_dec.data_ptr(), self._ws_dec.numel(),
+                                               q_dec))
+        for s, (pred_deltas, pred_probs) in zip(slots, outs):
+            s.done.record(q_dec)
+            s.inputs = s.inputs + (pred_deltas, pred_probs)
+            s.pending = None
 
     def result(self, ticket: int, wait: str = "host") -> Dict[str, torch.Tensor]:
         """Outputs of batch ``ticket``: ``roi_bboxes``, ``roi_pooled``, ``bboxes``, ``labels``, ``scores``.
@@ -196,6 +239,8 @@ class RoIPathPipeline:
         if not (self._count - self.depth <= ticket < self._count) or ticket < 0:
             raise ValueError(f"ticket {ticket} is not in flight (last {self.depth} of {self._count} submissions are)")
         slot = self.slots[ticket % self.depth]
+        if slot.pending is not None:
+            self.flush()
         if wait == "host":
             slot.done.synchronize()
         elif wait == "stream":
@@ -207,6 +252,7 @@ class RoIPathPipeline:
 
     def synchronize(self) -> None:
         """Block until every submitted batch is done."""
+        self.flush()
         for s in self.slots:
             if s.busy:
                 s.done.synchronize()
