@@ -219,6 +219,145 @@ __global__ __launch_bounds__(256) void crop_lds_kernel(const float *__restrict__
   }
 }
 
+// ---- x-deduplicated kernel: lane = one float4 of channels for a whole output row, taps shared along x in registers -----
+// The 2*cw column taps of a source row are left_0, right_0, left_1, ... ; consecutive entries are often the same column
+// (right_x == left_x+1's left, or an integral in_x).  Which ones is workgroup-uniform, so a lane loads a tap once and
+// keeps it for the next output pixel: scalar branches, no LDS, no barrier.
+template <int CW, int XB>
+__global__ __launch_bounds__(256) void crop_xdedupe_kernel(const float *__restrict__ image, int B, int H, int W, int C,
+                                                           const float *__restrict__ boxes, int n, int boxes_per_image,
+                                                           int ch, float extrap, float *__restrict__ out) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const unsigned q8 = (unsigned)n >> 3, r8 = (unsigned)n & 7;
+  const int box = (int)(((grp < r8) ? grp * (q8 + 1) : r8 * (q8 + 1) + (grp - r8) * q8) + slot);
+  const int bimg = box / boxes_per_image;
+  const bool img_ok = bimg >= 0 && bimg < B;
+  const float y1 = boxes[(long long)box * 4 + 0], x1 = boxes[(long long)box * 4 + 1];
+  const float y2 = boxes[(long long)box * 4 + 2], x2 = boxes[(long long)box * 4 + 3];
+  const float hm1 = (float)(H - 1), wm1 = (float)(W - 1);
+  // x parameters: lane i computes output column i, then everything is broadcast into SGPRs
+  float in_x;
+  {
+    if (CW > 1) {
+      float t = x2 - x1;
+      t = t * wm1;
+      const float ws = t / (float)(CW - 1);
+      const float t0 = x1 * wm1;
+      const float t1 = (float)lane * ws;
+      in_x = t0 + t1;
+    } else {
+      float t0 = x1 + x2;
+      t0 = 0.5f * t0;
+      in_x = t0 * wm1;
+    }
+  }
+  const bool vx_l = img_ok && (in_x >= 0.0f) && (in_x <= wm1);
+  const int left_l = vx_l ? (int)floorf(in_x) : 0, right_l = vx_l ? (int)ceilf(in_x) : 0;
+  const float lx_l = vx_l ? in_x - (float)left_l : 0.0f;
+  int col[2 * CW];
+  float lx[CW];
+  bool vx[CW];
+  bool ld[2 * CW];
+#pragma unroll
+  for (int x = 0; x < CW; ++x) {
+    col[2 * x] = __builtin_amdgcn_readlane(left_l, x);
+    col[2 * x + 1] = __builtin_amdgcn_readlane(right_l, x);
+    lx[x] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lx_l), x));
+    vx[x] = __builtin_amdgcn_readlane((int)vx_l, x) != 0;
+  }
+#pragma unroll
+  for (int k = 0; k < 2 * CW; ++k) {
+    const bool valid = vx[k >> 1];
+    const bool prev_valid = k > 0 && vx[(k - 1) >> 1];
+    ld[k] = valid && !(prev_valid && col[k] == col[k - 1]);
+  }
+  const int CV = C >> 2;
+  const unsigned pixb = (unsigned)C * 4u;
+  const char *__restrict__ img = reinterpret_cast<const char *>(image + (long long)(img_ok ? bimg : 0) * H * W * C);
+  f32x4 *__restrict__ dst = reinterpret_cast<f32x4 *>(out + (long long)box * ch * CW * C);
+  for (int c = tid; c < CV; c += blockDim.x) {
+    for (int y = 0; y < ch; ++y) {
+      float in_y;
+      if (ch > 1) {
+        float t = y2 - y1;
+        t = t * hm1;
+        const float hs = t / (float)(ch - 1);
+        const float t0 = y1 * hm1;
+        const float t1 = (float)y * hs;
+        in_y = t0 + t1;
+      } else {
+        float t0 = y1 + y2;
+        t0 = 0.5f * t0;
+        in_y = t0 * hm1;
+      }
+      const bool vy = __builtin_amdgcn_readfirstlane((int)(img_ok && (in_y >= 0.0f) && (in_y <= hm1))) != 0;
+      f32x4 *__restrict__ drow = dst + (long long)y * CW * CV + c;
+      if (!vy) {
+#pragma unroll
+        for (int x = 0; x < CW; ++x) __builtin_nontemporal_store((f32x4)(extrap), drow + x * CV);
+        continue;
+      }
+      const int top = __builtin_amdgcn_readfirstlane((int)floorf(in_y));
+      const int bot = __builtin_amdgcn_readfirstlane((int)ceilf(in_y));
+      const float ly = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(in_y - (float)top)));
+      const char *__restrict__ trow = img + (size_t)((unsigned)(top * W) * pixb);
+      const char *__restrict__ brow = img + (size_t)((unsigned)(bot * W) * pixb);
+      const bool two_rows = bot != top;
+      f32x4 carryT = (f32x4)(0.0f), carryB = (f32x4)(0.0f);  // last tap of the previous block of pixels
+#pragma unroll
+      for (int x0 = 0; x0 < CW; x0 += XB) {
+        constexpr int NE = 2 * XB;
+        f32x4 T[NE], Bt[NE];
+        // phase 1: every distinct tap of the block is issued (no use of a loaded value in between)
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int k = 2 * x0 + j;
+          T[j] = (f32x4)(0.0f);
+          Bt[j] = (f32x4)(0.0f);
+          if (k < 2 * CW) {
+            if (ld[k]) T[j] = *reinterpret_cast<const f32x4 *>(trow + (size_t)((unsigned)col[k] * pixb) + (size_t)c * 16);
+            if (ld[k] && two_rows) Bt[j] = *reinterpret_cast<const f32x4 *>(brow + (size_t)((unsigned)col[k] * pixb) + (size_t)c * 16);
+          }
+        }
+        // phase 2: a repeated column takes its neighbour's registers
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+          const int k = 2 * x0 + j;
+          if (k < 2 * CW && !ld[k]) {
+            T[j] = j > 0 ? T[j - 1] : carryT;
+            Bt[j] = j > 0 ? Bt[j - 1] : carryB;
+          }
+        }
+        if (!two_rows) {
+#pragma unroll
+          for (int j = 0; j < NE; ++j) Bt[j] = T[j];
+        }
+        carryT = T[NE - 1];
+        carryB = Bt[NE - 1];
+#pragma unroll
+        for (int xx = 0; xx < XB; ++xx) {
+          const int x = x0 + xx;
+          if (x < CW) {
+            const f32x4 tl = T[2 * xx], tr = T[2 * xx + 1], bl = Bt[2 * xx], br = Bt[2 * xx + 1];
+            f32x4 t = vsub(tr, tl);
+            t = t * lx[x];
+            const f32x4 tp = tl + t;
+            t = vsub(br, bl);
+            t = t * lx[x];
+            const f32x4 bt = bl + t;
+            t = vsub(bt, tp);
+            t = t * ly;
+            f32x4 v = tp + t;
+            if (!vx[x]) v = (f32x4)(extrap);
+            __builtin_nontemporal_store(v, drow + x * CV);
+          }
+        }
+      }
+    }
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 template <class F>
@@ -284,12 +423,11 @@ int main(int argc, char **argv) {
   ms = time_ms(prepass, iters);
   printf("params pre-pass                    %8.2f us\n", ms * 1e3);
 
-#define LDSK(QC) { \
-    const int nchunk = (C / 4 + QC - 1) / QC; \
-    ms = time_ms([&] { hipLaunchKernelGGL((crop_lds_kernel<QC>), dim3(n * nchunk), dim3(256), 0, 0, img, B, H, W, C, boxes, n, R, 7, 7, 0.f, out, nchunk); }, iters); \
-    printf("lds dedupe kernel QC=%d              %8.2f us  %7.1f GB/s\n", QC, ms * 1e3, alg / ms / 1e6); \
-    check("lds"); }
-  LDSK(8) LDSK(16) LDSK(4)
+#define XDD(NT, XB) { \
+    ms = time_ms([&] { hipLaunchKernelGGL((crop_xdedupe_kernel<7, XB>), dim3(n), dim3(NT), 0, 0, img, B, H, W, C, boxes, n, R, 7, 0.f, out); }, iters); \
+    printf("x-dedupe kernel NT=%d XB=%d             %8.2f us  %7.1f GB/s\n", NT, XB, ms * 1e3, alg / ms / 1e6); \
+    check("x-dedupe"); }
+  XDD(192, 4) XDD(128, 4) XDD(192, 2) XDD(128, 2) XDD(192, 3) XDD(64, 2)
 #define ROW(WPE) { \
     ms = time_ms([&] { hipLaunchKernelGGL((crop_row_kernel<WPE>), dim3(n * 7), dim3(256), 0, 0, img, B, H, W, C, boxes, n, R, 7, 7, 0.f, out); }, iters); \
     printf("row kernel wpe=%d                   %8.2f us  %7.1f GB/s\n", WPE, ms * 1e3, alg / ms / 1e6); \
