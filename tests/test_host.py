@@ -73,6 +73,30 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == syms
 
 
+def test_binding_table_has_the_header_arity():
+    """Every ctypes signature carries as many arguments as the declaration in include/frcnn_hip.h."""
+    text = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = dict(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text))
+    assert sorted(decls) == sorted(_lib.SIGNATURES)
+    for name, params in decls.items():
+        n = 0 if params.strip() in ("", "void") else params.count(",") + 1
+        assert n == len(_lib.SIGNATURES[name][1]), f"{name}: header has {n} parameters, the binding {len(_lib.SIGNATURES[name][1])}"
+
+
+def test_multi_entry_points_validate_on_the_host():
+    """The grouped entry points reject a bad pointer table / group count before touching a device."""
+    lib = _lib.lib()
+    one = (ctypes.c_void_p * 1)(None)
+    f4 = _lib.float4([0.1, 0.1, 0.2, 0.2])
+    assert lib.frcnn_crop_and_resize_multi(None, None, None, 1, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None) == _lib.FRCNN_EINVAL
+    assert lib.frcnn_crop_and_resize_multi(one, one, one, 5, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None) == _lib.FRCNN_EINVAL
+    assert b"groups" in lib.frcnn_last_error()
+    assert lib.frcnn_crop_and_resize_multi(one, one, one, 1, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None) == _lib.FRCNN_EINVAL  # null entry
+    assert lib.frcnn_roi_bbox_multi(one, one, None, f4, 0, 1, 9, 4, 2, 0.7, one, None, 0, None) == _lib.FRCNN_EINVAL
+    assert lib.frcnn_decoder_multi(one, one, one, f4, 9, 1, 4, 3, 2, 0.5, 0.5, one, one, one, None, 0, None) == _lib.FRCNN_EINVAL
+
+
 def test_no_torch_types_cross_the_boundary():
     text = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
     assert "torch" not in text.lower() and "at::" not in text and "hip/hip_runtime" not in text
