@@ -34,7 +34,9 @@ import synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
-TIME_EVERY = int(os.environ.get("FRCNN_BENCH_TIME_EVERY", "1"))  # pipeline mode: bracket every n-th crop launch with events
+# pipeline mode: every n-th crop launch of the timed region is bracketed with HIP events on its stream (each pair adds two
+# packets to the critical gap between consecutive crop launches: bracketing all of them costs 2-4 % of the throughput)
+TIME_EVERY = int(os.environ.get("FRCNN_BENCH_TIME_EVERY", "4"))
 
 # BASELINE config 2
 CFG = dict(backbone="mobilenet_v2", B=16, G=32, C=576, K=6000, R=300, L=21, pool=7)
