@@ -24,7 +24,6 @@ Host cost per batch is three C-ABI calls and a handful of event operations: outp
 
 from __future__ import annotations
 
-import ctypes
 import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
@@ -70,7 +69,7 @@ class RoIPathPipeline:
         if not 1 <= crop_group <= 4 or crop_group > depth:
             raise ValueError("crop_group must be 1..4 and at most depth")
         self.crop_group = crop_group
-        self._pending: List[int] = []  # slot indices whose proposals are enqueued and whose crop + Decoder are not yet
+        self._pending: List[int] = []  # slots of submitted batches that wait for their group to be enqueued (flush)
         self.roi_bbox, self.roi_pooling, self.decoder = roi_bbox, roi_pooling, decoder
         self.device = roi_bbox.anchors.device
         if self.device.type != "cuda":
@@ -137,7 +136,6 @@ class RoIPathPipeline:
         the crop kernel on its stream (with ``crop_group > 1``: around the group's launch, taken from the first batch
         of the group that carries them).
         """
-        lib = _lib.lib()
         dev = self.device
         deltas = _lib.device_tensor(rpn_bbox_deltas, torch.float32, dev)
         scores = _lib.device_tensor(rpn_labels, torch.float32, dev)
