@@ -144,6 +144,87 @@ def test_iou_map_batched_and_nan(pkg):
     assert_bits(got, want, "iou_map batched")
 
 
+def _fastdiv_boxes(rng, shape, kind):
+    """Boxes that stress the IoU arithmetic: overlaps of a few ulps, equal edges, magnitudes from 2^-60 to 2^60, negative
+    areas, non-finite coordinates."""
+    n = int(np.prod(shape))
+    y1 = rng.random(n).astype(np.float32)
+    x1 = rng.random(n).astype(np.float32)
+    h = rng.random(n).astype(np.float32)
+    w = rng.random(n).astype(np.float32)
+    if kind == "slivers":        # overlaps and sides down to a few ulps
+        h = np.float32(2.0) ** rng.integers(-22, 1, n).astype(np.float32)
+        w = np.float32(2.0) ** rng.integers(-22, 1, n).astype(np.float32)
+    elif kind == "grid":         # coordinates on a coarse grid: many equal edges, zero-width overlaps, identical boxes
+        y1, x1 = (np.round(y1 * 8) / 8).astype(np.float32), (np.round(x1 * 8) / 8).astype(np.float32)
+        h, w = (np.round(h * 4) / 8).astype(np.float32), (np.round(w * 4) / 8).astype(np.float32)
+    elif kind == "extremes":     # both ends of the nice range, and just outside it
+        scale = np.float32(2.0) ** rng.integers(-21, 3, n).astype(np.float32)
+        y1, x1, h, w = y1 * scale, x1 * scale, h * scale, w * scale
+    elif kind == "rough":        # negative areas, huge and tiny magnitudes, infinities: the exact divide must take over
+        scale = np.float32(2.0) ** rng.integers(-60, 60, n).astype(np.float32)
+        y1, x1, h, w = y1 * scale, x1 * scale, (h - np.float32(0.3)) * scale, (w - np.float32(0.3)) * scale
+    b = np.stack([y1, x1, y1 + h, x1 + w], axis=-1).astype(np.float32)
+    return b.reshape(*shape, 4)
+
+
+@pytest.mark.parametrize("kind", ["plain", "slivers", "grid", "extremes", "rough"])
+def test_iou_map_range_stress(pkg, kind):
+    """Every quotient of the materialised map is the correctly rounded one (= the oracle's) over the whole range of
+    operands, NaN / infinity handling included (the wave-uniform fast paths of csrc/iou_map.hip must not change a bit)."""
+    rng = np.random.default_rng({"plain": 1, "slivers": 2, "grid": 3, "extremes": 4, "rough": 5}[kind])
+    B, N, M = 6, 4096, 100
+    bb = _fastdiv_boxes(rng, (B, N), kind)
+    gt = _fastdiv_boxes(rng, (B, M), kind)
+    gt[:, 60:] = 0.0                       # zero padding, as the data pipeline produces
+    if kind == "grid":
+        gt[:, :20] = bb[:, :20]            # identical boxes: IoU exactly 1
+    if kind == "rough":
+        bb[1, 7] = [0.1, 0.1, np.inf, 0.5]
+        gt[2, 3] = [np.nan, 0.1, 0.4, 0.5]
+        bb[3] = _fastdiv_boxes(rng, (N,), "plain")   # a nice image between rough ones
+        gt[3] = _fastdiv_boxes(rng, (M,), "plain")
+    want = oracle.generate_iou_map(bb, gt)
+    assert_bits(pkg.bbox_utils.generate_iou_map(dev(bb), dev(gt)), want, f"iou_map {kind} (batched boxes)")
+    want1 = oracle.generate_iou_map(bb[0], gt)
+    assert_bits(pkg.bbox_utils.generate_iou_map(dev(bb[0]), dev(gt)), want1, f"iou_map {kind} (shared boxes)")
+
+
+@pytest.mark.parametrize("kind", ["plain", "slivers", "grid", "extremes", "rough"])
+def test_iou_map_reduce_range_stress(pkg, kind):
+    """frcnn_iou_map_reduce (the fused reductions of utils/train_utils.py:177-179) through the C ABI on the same inputs:
+    row max / first argmax / first column argmax must equal those of the oracle's materialised map."""
+    from tf_faster_rcnn_amd import _lib
+
+    rng = np.random.default_rng({"plain": 11, "slivers": 12, "grid": 13, "extremes": 14, "rough": 15}[kind])
+    B, N, M = 3, 1500, 37
+    bb = _fastdiv_boxes(rng, (B, N), kind)
+    gt = _fastdiv_boxes(rng, (B, M), kind)
+    gt[:, 30:] = 0.0
+    if kind == "rough":
+        bb[1] = _fastdiv_boxes(rng, (N,), "plain")
+        gt[1] = _fastdiv_boxes(rng, (M,), "plain")
+        bb[1, 100:164] = 0.0               # one wave of zero boxes (0/0 = NaN against the padded gts) inside a nice image
+    iou = oracle.generate_iou_map(bb, gt)
+    filled = np.where(np.isnan(iou), -np.inf, iou)
+    want_max = filled.max(axis=2)
+    want_max = np.where(np.isinf(want_max), np.float32(-3.402823466e38), want_max).astype(np.float32)
+    want_row = filled.argmax(axis=2).astype(np.int32)
+    want_col = filled.argmax(axis=1).astype(np.int32)
+    lib = _lib.lib()
+    d_bb, d_gt = dev(bb), dev(gt)
+    mx = torch.empty((B, N), dtype=torch.float32, device="cuda")
+    ar = torch.empty((B, N), dtype=torch.int32, device="cuda")
+    ac = torch.empty((B, M), dtype=torch.int32, device="cuda")
+    ws = torch.empty(max(1, lib.frcnn_iou_reduce_workspace_bytes(B, N, M)), dtype=torch.uint8, device="cuda")
+    _lib.check(lib.frcnn_iou_map_reduce(d_bb.data_ptr(), 1, d_gt.data_ptr(), B, N, M, mx.data_ptr(), ar.data_ptr(), ac.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert_bits(mx, want_max, f"iou_map_reduce {kind}: row max")
+    assert_bits(ar, want_row, f"iou_map_reduce {kind}: row argmax")
+    assert_bits(ac, want_col, f"iou_map_reduce {kind}: column argmax")
+
+
 # ------------------------------------------------------------------------------------------------
 # top-k
 # ------------------------------------------------------------------------------------------------
