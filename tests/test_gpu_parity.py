@@ -720,6 +720,42 @@ def test_config1_batch1_full_path(pkg):
 
 
 # ------------------------------------------------------------------------------------------------
+# committed golden vectors (tests/golden/*.npz, written by tests/golden/make_golden.py): the HIP path on the committed
+# inputs against the committed outputs -- no oracle call in between
+# ------------------------------------------------------------------------------------------------
+def test_golden_vectors_through_the_hip_path(pkg):
+    import os
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(golden, "inference_path.npz"))
+    hp = synth.hyper_params(feature_map_shape=8, pre_nms_topn=64, test_nms_topn=16)
+    assert_bits(pkg.bbox_utils.generate_anchors(hp), g["anchors"], "golden anchors")
+    rois = pkg.faster_rcnn.RoIBBox(dev(g["anchors"]), "inference", hp)([dev(g["deltas"]), dev(g["scores"])])
+    assert_bits(rois, g["rois"], "golden RoIBBox")
+    pooled = pkg.faster_rcnn.RoIPooling(hp)([dev(g["fm"]), rois])
+    assert_bits(pooled, g["pooled"], "golden RoIPooling")
+    boxes, labels, scores = pkg.faster_rcnn.Decoder(hp["variances"], 5)([rois, dev(g["head_deltas"]), dev(g["head_probs"])])
+    assert_bits(boxes, g["det_boxes"], "golden Decoder boxes")
+    assert_bits(labels, g["det_labels"], "golden Decoder labels")
+    assert_bits(scores, g["det_scores"], "golden Decoder scores")
+
+    t = np.load(os.path.join(golden, "rpn_targets.npz"))
+    hp_t = synth.hyper_params(feature_map_shape=8, total_pos_bboxes=8, total_neg_bboxes=8)
+    assert_bits(pkg.bbox_utils.generate_iou_map(dev(t["anchors"]), dev(t["gt_boxes"])), t["iou_map"], "golden iou_map")
+    d, l = pkg.train_utils.calculate_rpn_actual_outputs(dev(t["anchors"]), dev(t["gt_boxes"]), dev(t["gt_labels"]), hp_t,
+                                                        random_masks=(dev(t["rnd_pos"]), dev(t["rnd_neg"])))
+    assert_bits(d, t["bbox_deltas"], "golden rpn deltas")
+    assert_bits(l, t["bbox_labels"], "golden rpn labels")
+
+    r = np.load(os.path.join(golden, "roi_delta.npz"))
+    hp_r = synth.hyper_params(total_labels=5, total_pos_bboxes=4, total_neg_bboxes=4)
+    rd, rl = pkg.faster_rcnn.RoIDelta(hp_r)([dev(r["rois"]), dev(r["gt_boxes"]), dev(r["gt_labels"])],
+                                            random_masks=(dev(r["rnd_pos"]), dev(r["rnd_neg"])))
+    assert_bits(rd, r["roi_bbox_deltas"], "golden RoIDelta deltas")
+    assert_bits(rl, r["roi_bbox_labels"], "golden RoIDelta labels")
+
+
+# ------------------------------------------------------------------------------------------------
 # stage pipeline over streams
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("depth,heads_callable,crop_group", [(1, False, 1), (3, False, 1), (4, True, 1), (4, False, 2),
