@@ -56,7 +56,10 @@ def pmc_traffic_bytes():
 
     def avg(pattern, counter):
         vals = []
-        for path in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+        # the most recent pass only: per-round files are named r<round>_<letter>_pmc_*, the first pass r01_pmc_*
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)),
+                       key=lambda q: tuple((os.path.basename(q).split("_pmc_")[0] + "_").split("_")[:2]))  # (round, letter or "")
+        for path in paths[-1:]:
             with open(path) as fh:
                 for row in csv.DictReader(fh):
                     if row["Counter_Name"] == counter and "crop_resize_kernel" in row["Kernel_Name"]:
