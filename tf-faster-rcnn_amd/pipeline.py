@@ -37,8 +37,67 @@ Heads = Union[Callable[[torch.Tensor, torch.Tensor], Tuple[torch.Tensor, torch.T
               Tuple[torch.Tensor, torch.Tensor]]
 
 
+def _stage_streams(device: torch.device, want: int = 3) -> List[torch.cuda.Stream]:
+    """``want`` streams that share a hardware queue neither with each other nor with the caller's stream.
+
+    A process has four hardware queues (GPU_MAX_HW_QUEUES) and HIP deals streams onto them; which queue a new stream gets
+    depends on the streams other code (torch's pool, RCCL) made before.  Two stage streams on one queue serialise behind
+    each other's event waits: measured 7 % (two of the small stages) to 14 % (the pooling stage involved) of the pipeline's
+    throughput, depending only on how many streams existed before the pipeline was built.  So the streams are probed: a
+    stream spins for a moment, and every candidate whose marker completes meanwhile sits on a different queue.  Falls back
+    to the first candidates when the probe is inconclusive.
+    """
+    cands = [torch.cuda.Stream(device) for _ in range(8)]
+    cur = torch.cuda.current_stream(device)
+    for s in cands:  # first use creates the queue: keep that out of the probe
+        torch.cuda.Event().record(s)
+    torch.cuda.synchronize(device)
+
+    def independent_of(busy: List[torch.cuda.Stream], pool: List[torch.cuda.Stream]) -> Optional[List[torch.cuda.Stream]]:
+        cycles = 2_000_000
+        for _ in range(3):
+            ends = []
+            for b in busy:
+                with torch.cuda.stream(b):
+                    torch.cuda._sleep(cycles)
+                    e = torch.cuda.Event()
+                    e.record(b)
+                    ends.append(e)
+            marks = []
+            for s in pool:
+                e = torch.cuda.Event()
+                e.record(s)
+                marks.append(e)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 300e-6:
+                pass
+            free = [m.query() for m in marks]
+            still_spinning = not any(e.query() for e in ends)
+            torch.cuda.synchronize(device)
+            if still_spinning:
+                return [s for s, f in zip(pool, free) if f]
+            cycles *= 8  # the spin was over before the markers were looked at: spin longer
+        return None
+
+    chosen: List[torch.cuda.Stream] = []
+    pool = list(cands)
+    try:
+        while len(chosen) < want:
+            pool = independent_of([cur] + chosen if not chosen else [chosen[-1]], pool)
+            if not pool:
+                break
+            chosen.append(pool.pop(0))
+    except Exception:  # the probe must never keep the pipeline from being built
+        chosen = []
+    if os.environ.get("FRCNN_PIPE_DEBUG"):
+        print(f"[pipeline] stage-stream probe: chose {[cands.index(s) for s in chosen]} of {len(cands)} candidates", flush=True)
+    if len(chosen) < want:
+        return cands[:want]
+    return chosen
+
+
 class _Slot:
-    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy", "pending")
+    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy", "pending", "wait_in")
 
     def __init__(self) -> None:
         self.rois = self.pooled = self.boxes = self.labels = self.scores = None
@@ -46,6 +105,7 @@ class _Slot:
         self.inputs: Any = None
         self.busy = False
         self.pending: Any = None  # (fm, heads, timing) while the batch waits for its group's crop launch
+        self.wait_in = False      # the proposal stage must wait for an event recorded on the caller's stream
 
 
 class RoIPathPipeline:
@@ -76,7 +136,7 @@ class RoIPathPipeline:
             raise RuntimeError("RoIPathPipeline needs a ROCm GPU; there is no CPU fallback.")
         self.depth = depth
         with torch.cuda.device(self.device):
-            self.s_prop, self.s_pool, self.s_dec = (torch.cuda.Stream(self.device) for _ in range(3))
+            self.s_prop, self.s_pool, self.s_dec = _stage_streams(self.device)
             self.slots: List[_Slot] = [_Slot() for _ in range(depth)]
             # stream-to-stream events: device-scope release (no L2 write-back behind the kernel they follow)
             self._ev_in = [_lib.HipEvent() for _ in range(depth)]
@@ -149,8 +209,15 @@ class RoIPathPipeline:
             t_wait = time.perf_counter()
             slot.done.synchronize()  # back-pressure; also makes dropping the old inputs safe
             self.wait_seconds += time.perf_counter() - t_wait
-        ev_in = self._ev_in[k]
-        ev_in.record(torch.cuda.current_stream(dev).cuda_stream)  # inputs were produced on the caller's stream
+        # The inputs were produced on the caller's stream: the proposal stage waits for an event recorded there -- unless
+        # that stream is idle, in which case they are complete and the stream is left alone.  (A process has four hardware
+        # queues, GPU_MAX_HW_QUEUES; when the caller's stream shares one with the pooling or Decoder stream, which depends on
+        # how many streams other libraries created first, every marker recorded on it queues behind that stage's kernels:
+        # measured 7-14 % of the throughput.)
+        cur = torch.cuda.current_stream(dev)
+        slot.wait_in = not cur.query()
+        if slot.wait_in:
+            self._ev_in[k].record(cur.cuda_stream)
         slot.pending = (fm, heads, timing)
         slot.inputs = (deltas, scores, fm)  # keep alive until the slot comes round again
         slot.busy = True
@@ -180,7 +247,8 @@ class RoIPathPipeline:
         tab = _lib.ptr_table
 
         for k in ks:
-            self._ev_in[k].wait(q_prop)
+            if self.slots[k].wait_in:
+                self._ev_in[k].wait(q_prop)
         if "prop" not in self._skip:
             _lib.check(lib.frcnn_roi_bbox_multi(tab([s.inputs[0] for s in slots]), tab([s.inputs[1] for s in slots]),
                                                 self.roi_bbox.anchors.data_ptr(), self._var_prop, n, B, N, self._K, R,
