@@ -803,6 +803,41 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
 
 
+@pytest.mark.parametrize("schedule", ["unfused", "bitmask"])
+def test_pipeline_groups_on_schedules_without_a_grouped_form(pkg, monkeypatch, schedule):
+    """crop_group > 1 where frcnn_roi_bbox_multi / frcnn_decoder_multi have no grouped launch (the generic sort -> NMS
+    pipelines, the whole-chip bitmask NMS): they run one call per batch on the shared workspace; results as sequential."""
+    from tf_faster_rcnn_amd import pipeline
+
+    B, G, C, L = 2, 12, 16, 4
+    R = 24 if schedule == "unfused" else 600
+    if schedule == "unfused":
+        monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+        monkeypatch.setenv("FRCNN_DECODER_UNFUSED", "1")
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=1000, test_nms_topn=R, total_labels=L)
+    anchors = oracle.generate_anchors(hp)
+    roi_bbox = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)
+    roi_pool = pkg.faster_rcnn.RoIPooling(hp)
+    decoder = pkg.faster_rcnn.Decoder(hp["variances"], L)
+    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=4, crop_group=2)
+    batches = []
+    for seed in range(3):
+        deltas, scores = synth.rpn_outputs(40 + seed, B, G)
+        hd, hpb = synth.head_outputs(40 + seed, B, R, L)
+        batches.append(tuple(dev(a) for a in (deltas, scores, synth.feature_map(40 + seed, B, G, C), hd, hpb)))
+    for b in batches:
+        pipe.submit(b[0], b[1], b[2], (b[3], b[4]))
+    got = [{k: v.clone() for k, v in pipe.result(i).items()} for i in range(3)]
+    pipe.synchronize()
+    for i, b in enumerate(batches):
+        seq = pipeline.run_sequential(roi_bbox, roi_pool, decoder, b)
+        for name in ("roi_bboxes", "roi_pooled", "bboxes", "labels", "scores"):
+            assert_bits(got[i][name], seq[name].cpu().numpy(), f"grouped pipeline ({schedule}) batch {i} {name}")
+        want = oracle.roi_bbox(b[0].cpu().numpy(), b[1].cpu().numpy(), anchors, hp["variances"], 1000, R, hp["nms_iou_threshold"])
+        assert_bits(got[i]["roi_bboxes"], want, f"grouped pipeline ({schedule}) batch {i} rois vs oracle")
+
+
 @pytest.mark.parametrize("groups,C,H", [(1, 32, 9), (2, 576, 12), (3, 20, 7), (4, 64, 5), (2, 6, 8)])
 def test_crop_and_resize_multi_matches_oracle(pkg, groups, C, H):
     """frcnn_crop_and_resize_multi through the C ABI: `groups` (image, boxes, out) triples in one call, each bit-identical
