@@ -803,6 +803,36 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
 
 
+def test_pipeline_grouped_launches_at_config2_size(pkg):
+    """bench.py's default schedule (2 batches per launch of each stage, 8 in flight) at the full BASELINE config 2 size:
+    every output of every batch is bit-identical to the three layers called in order (whose results the other tests pin
+    to the oracle at this size)."""
+    from tf_faster_rcnn_amd import pipeline
+
+    B, G, C, L, R = 16, 32, 576, 21, 300
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp["total_labels"] = L
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    roi_bbox = pkg.faster_rcnn.RoIBBox(anchors, "inference", hp)
+    roi_pool = pkg.faster_rcnn.RoIPooling(hp)
+    decoder = pkg.faster_rcnn.Decoder(hp["variances"], L)
+    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=8, crop_group=2)
+    batches = []
+    for seed in range(3):
+        deltas, scores = synth.rpn_outputs(70 + seed, B, G)
+        hd, hpb = synth.head_outputs(70 + seed, B, R, L)
+        batches.append(tuple(dev(a) for a in (deltas, scores, synth.feature_map(70 + seed, B, G, C), hd, hpb)))
+    for b in batches:
+        pipe.submit(b[0], b[1], b[2], (b[3], b[4]))
+    pipe.synchronize()
+    for i, b in enumerate(batches):
+        got = pipe.result(i)
+        seq = pipeline.run_sequential(roi_bbox, roi_pool, decoder, b)
+        for name in ("roi_bboxes", "roi_pooled", "bboxes", "labels", "scores"):
+            assert torch.equal(got[name].view(torch.int32), seq[name].view(torch.int32)), f"config 2 grouped batch {i} {name}"
+        assert int((got["roi_bboxes"].abs().sum(-1) > 0).sum()) > B * R // 2  # real proposals, not padding
+
+
 @pytest.mark.parametrize("schedule", ["unfused", "bitmask"])
 def test_pipeline_groups_on_schedules_without_a_grouped_form(pkg, monkeypatch, schedule):
     """crop_group > 1 where frcnn_roi_bbox_multi / frcnn_decoder_multi have no grouped launch (the generic sort -> NMS
