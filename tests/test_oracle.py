@@ -213,6 +213,42 @@ def test_numpy_restatement_crop_and_nms():
     assert bits_equal(b[0, :len(sel)], bx[sel]) and bits_equal(s[0, :len(sel)], sc[sel])
 
 
+def test_crop_and_resize_agrees_with_torch_grid_sample():
+    """An implementation nobody here wrote: torch.nn.functional.grid_sample(bilinear, align_corners=True) samples the same
+    grid as tf.image.crop_and_resize for boxes inside the image (pixel i of H at i / (H - 1)).  Evaluated in fp64 it must
+    agree with the fp32 oracle to a few ulps -- a cross-check of the sampling coordinates and the lerp weights (the
+    extrapolation rule differs between the two and is not exercised: every sample lies inside)."""
+    torch = pytest.importorskip("torch")
+    import torch.nn.functional as F
+
+    rng = np.random.default_rng(0)
+    B, H, W, C, R = 2, 9, 11, 5, 6
+    fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    want = oracle.roi_pooling(fm, rois, (7, 7))
+    t = torch.from_numpy(fm).permute(0, 3, 1, 2).double()
+    for b in range(B):
+        for r in range(R):
+            y1, x1, y2, x2 = (float(v) for v in rois[b, r])
+            ys = torch.linspace(0, 1, 7, dtype=torch.float64) * (y2 - y1) + y1
+            xs = torch.linspace(0, 1, 7, dtype=torch.float64) * (x2 - x1) + x1
+            gy, gx = torch.meshgrid(ys * 2 - 1, xs * 2 - 1, indexing="ij")
+            o = F.grid_sample(t[b:b + 1], torch.stack([gx, gy], -1)[None], mode="bilinear", padding_mode="zeros",
+                              align_corners=True)
+            np.testing.assert_allclose(want[b, r], o[0].permute(1, 2, 0).numpy(), rtol=0, atol=1e-5)
+
+
+def test_top_k_agrees_with_torch_topk():
+    """torch.topk(sorted=True) on rows of distinct values: same values, same indices as the oracle's tf.nn.top_k (tie order
+    is the one thing the two libraries do not share, hence distinct values)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(4)
+    s = rng.permutation(3 * 5000).reshape(3, 5000).astype(np.float32) / np.float32(16384)
+    vals, idx = oracle.top_k(s, 700)
+    tv, ti = torch.topk(torch.from_numpy(s), 700, dim=1, largest=True, sorted=True)
+    assert bits_equal(vals, tv.numpy()) and (idx == ti.numpy()).all()
+
+
 # ---- committed golden vectors -----------------------------------------------------------------------------
 def test_golden_inference_path():
     g = np.load(os.path.join(GOLDEN, "inference_path.npz"))
