@@ -215,8 +215,10 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    crop_ms = float(np.mean([a.elapsed_time(b) for i, (a, b) in enumerate(zip(ev0, ev1))
-                             if args.mode == "sequential" or i % (TIME_EVERY * group) == 0])) if args.steps else float("nan")
+    crop_samples = [a.elapsed_time(b) for i, (a, b) in enumerate(zip(ev0, ev1))
+                    if args.mode == "sequential" or i % (TIME_EVERY * group) == 0]
+    crop_ms = float(np.mean(crop_samples)) if crop_samples else float("nan")
+    crop_pct = [round(float(v), 5) for v in np.percentile(crop_samples, [10, 50, 90])] if crop_samples else None
     launch_batches = group if args.mode == "pipeline" else 1  # batches one crop launch covers
     other = None
     if world == 1 and not args.no_other_schedule:  # the other schedule, same K steps, reported beside the headline (not part of `value`)
@@ -252,7 +254,8 @@ def main() -> None:
                                     else "sequential on one stream")},
             "roofline": {"kernel": "crop_resize_kernel<4>", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (lambda t: None if t is None else t * launch_batches)(pmc_traffic_bytes()), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5)},
+                         "traffic": (lambda t: None if t is None else t * launch_batches)(pmc_traffic_bytes()), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5),
+                         "launch_ms_p10_p50_p90": crop_pct, "launches_timed": len(crop_samples)},
         }
         if other is not None:
             result["other_schedule"] = other
