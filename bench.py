@@ -124,6 +124,9 @@ def main() -> None:
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--crop-group", type=int, default=2,
                     help="pipeline mode: consecutive batches that share one launch per stage (the *_multi entry points)")
+    ap.add_argument("--no-host-gather", action="store_true",
+                    help="leave the small per-image outputs (RoIs, detections) on the GPU instead of copying them to pinned "
+                         "host memory every step (the sharded deployment's final host gather, SURVEY.md 8e)")
     ap.add_argument("--dist-backend", default="nccl", help="process-group backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--device", type=int, default=None,
                     help="GPU index for this rank (default LOCAL_RANK); lets a 1-GPU box rehearse the N-rank launch path")
@@ -167,6 +170,11 @@ def main() -> None:
 
     cur = torch.cuda.current_stream(device).cuda_stream
 
+    gather = not args.no_host_gather
+    T = int(decoder.max_total_size)
+    host_out = [torch.empty(shape, dtype=torch.float32, pin_memory=True)
+                for shape in ((cfg["B"], cfg["R"], 4), (cfg["B"], T, 4), (cfg["B"], T), (cfg["B"], T))] if gather else []
+
     def step_sequential(i=None):
         rois = roi_bbox([deltas, scores])
         if i is not None:
@@ -175,10 +183,12 @@ def main() -> None:
         if i is not None:
             ev1[i].record(cur)
         dets = decoder([rois, hd, hp])
+        for dst, src in zip(host_out, (rois,) + tuple(dets)):  # the host gather of the small outputs (copy kernels)
+            pkg._lib.check(pkg._lib.lib().frcnn_gather_copy(src.data_ptr(), dst.data_ptr(), src.numel() * 4, cur))
         return pooled, dets
 
     group = args.crop_group
-    pipe = pkg.pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=args.depth, crop_group=group)
+    pipe = pkg.pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=args.depth, crop_group=group, host_outputs=gather)
 
     def step_pipeline(i=None):
         # every step is a full pass (RoIBBox -> RoIPooling -> Decoder) over its batch; the stages of up to
@@ -251,7 +261,9 @@ def main() -> None:
                        "global_batch": cfg["B"] * world, "parallelism": f"dp{world} over images, no collectives",
                        "schedule": (f"stage pipeline on 3 HIP streams, {args.depth} batches in flight, "
                                     f"{group} consecutive batch(es) per launch of each stage" if args.mode == "pipeline"
-                                    else "sequential on one stream")},
+                                    else "sequential on one stream"),
+                       "host_gather": ("RoIs and detections of every batch copied to pinned host memory inside the timed "
+                                       "region; pooled features stay on the GPU") if gather else "none"},
             "roofline": {"kernel": "crop_resize_kernel<4>", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": (lambda t: None if t is None else t * launch_batches)(pmc_traffic_bytes()), "bytes_per_launch": crop_bytes, "avg_launch_ms": round(crop_ms, 5),

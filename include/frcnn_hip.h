@@ -190,6 +190,13 @@ int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_
                     float *out_deltas, float *out_labels, void *workspace, size_t workspace_bytes,
                     frcnn_stream_t stream);
 
+/* ---- host gather ----------------------------------------------------------------------- */
+/* Copy `bytes` bytes from device memory to `dst`, which may be pinned host memory mapped into the device (hipHostMalloc):
+ * the "final host gather" of the small per-image outputs in a deployment sharded over GPUs (there is no counterpart in the
+ * reference, which is single-device; Keras' predict() returns host arrays: faster_rcnn_predictor.py:56).  A kernel on
+ * `stream`, not a copy-engine transfer: it orders like any other stage.  Both pointers 16-byte aligned. */
+int frcnn_gather_copy(const void *src, void *dst, size_t bytes, frcnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -772,7 +772,8 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
     roi_bbox = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)
     roi_pool = pkg.faster_rcnn.RoIPooling(hp)
     decoder = pkg.faster_rcnn.Decoder(hp["variances"], L)
-    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=depth, crop_group=crop_group)
+    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, decoder, depth=depth, crop_group=crop_group,
+                                    host_outputs=heads_callable)  # the pinned host copies ride along on half of the cases
     batches = []
     for seed in range(7):
         deltas, scores = synth.rpn_outputs(seed, B, G)
@@ -787,9 +788,13 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
         assert t == i
         if i >= depth - 1:  # consume the oldest batch still in flight
             j = i - (depth - 1)
-            got[j] = {k: v.clone() for k, v in pipe.result(j).items()}
+            res = pipe.result(j)
+            got[j] = {k: v.clone() for k, v in res.items() if k != "host"}
+            if heads_callable:  # host_outputs: the pinned copies are complete once result(wait="host") returns
+                for name, h in res["host"].items():
+                    assert_bits(h, res[name].cpu().numpy(), f"pipeline batch {j} host copy of {name}")
     for j in range(len(batches) - (depth - 1), len(batches)):
-        got[j] = {k: v.clone() for k, v in pipe.result(j, wait="stream").items()}
+        got[j] = {k: v.clone() for k, v in pipe.result(j, wait="stream").items() if k != "host"}
     pipe.synchronize()
     with pytest.raises(ValueError):
         pipe.result(len(batches))

@@ -74,6 +74,17 @@ __global__ __launch_bounds__(256) void encode_kernel(const float4 *__restrict__ 
   out[i] = o;
 }
 
+// The "final host gather" of the sharded deployment for the small per-image outputs: a plain copy kernel
+// whose destination may be pinned host memory (device-mapped), so that the gather is one more kernel on the stage's stream
+// instead of a copy-engine transfer with its cross-queue synchronisation.
+__global__ __launch_bounds__(256) void gather_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, long long n16,
+                                                          const unsigned char *__restrict__ src_tail,
+                                                          unsigned char *__restrict__ dst_tail, int tail) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -144,6 +155,22 @@ int frcnn_encode_boxes(const float *bboxes, int bboxes_batched, const float *gt_
                        (long long)N, total, 1.0f, 1.0f, 1.0f, 1.0f);
   }
   return check_launch("encode_boxes");
+}
+
+
+int frcnn_gather_copy(const void *src, void *dst, size_t bytes, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(src && dst, "gather_copy: null pointer");
+  FRCNN_REQUIRE(aligned_to(src, 16) && aligned_to(dst, 16), "gather_copy: pointers must be 16-byte aligned");
+  FRCNN_REQUIRE(bytes < ((size_t)1 << 40), "gather_copy: size too large");
+  if (bytes == 0) return FRCNN_OK;
+  const long long n16 = (long long)(bytes / 16);
+  const int tail = (int)(bytes % 16);
+  const long long blocks = (n16 + 255) / 256 > 0 ? (n16 + 255) / 256 : 1;
+  hipLaunchKernelGGL(gather_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(dst), n16,
+                     reinterpret_cast<const unsigned char *>(src) + n16 * 16, reinterpret_cast<unsigned char *>(dst) + n16 * 16,
+                     tail);
+  return check_launch("gather_copy");
 }
 
 }  // extern "C"
