@@ -808,6 +808,25 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
 
 
+@pytest.mark.parametrize("nbytes", [16, 4096 + 7, 154_000, 3])
+def test_gather_copy_into_pinned_host_memory(pkg, nbytes):
+    """frcnn_gather_copy: a kernel that copies device memory into device-mapped pinned host memory (and device to device),
+    any byte count."""
+    from tf_faster_rcnn_amd import _lib
+
+    rng = np.random.default_rng(nbytes)
+    data = rng.integers(0, 256, nbytes, dtype=np.uint8)
+    src = torch.from_numpy(data).cuda()
+    host = torch.zeros(nbytes + 16, dtype=torch.uint8, pin_memory=True)
+    devdst = torch.zeros(nbytes + 16, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().frcnn_gather_copy(src.data_ptr(), host.data_ptr(), nbytes, stream))
+    _lib.check(_lib.lib().frcnn_gather_copy(src.data_ptr(), devdst.data_ptr(), nbytes, stream))
+    torch.cuda.synchronize()
+    assert (host.numpy()[:nbytes] == data).all() and not host.numpy()[nbytes:].any()
+    assert (devdst.cpu().numpy()[:nbytes] == data).all() and not devdst.cpu().numpy()[nbytes:].any()
+
+
 def test_pipeline_grouped_launches_at_config2_size(pkg):
     """bench.py's default schedule (2 batches per launch of each stage, 8 in flight) at the full BASELINE config 2 size:
     every output of every batch is bit-identical to the three layers called in order (whose results the other tests pin
