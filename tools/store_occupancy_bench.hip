@@ -59,6 +59,32 @@ __global__ __launch_bounds__(256) void store_chunk_map_kernel(f32x4 *out, long l
   const long long e = (long long)c * 256 + threadIdx.x;
   if (e < n4) __builtin_nontemporal_store((f32x4)(v), &out[e]);
 }
+// the box pattern with the library kernel's XCD-aware remap: XCD g (= blockIdx % 8) owns the contiguous box range g
+template <int T, int U>
+__global__ __launch_bounds__(T) void store_crop_xcd_kernel(f32x4 *out, int n, float v) {
+  const int per = 7056;
+  const int grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int q = n >> 3, r = n & 7;
+  const int box = ((grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + slot;
+  f32x4 *dst = out + (long long)box * per;
+  f32x4 x = (f32x4)(v);
+  int e = threadIdx.x;
+  for (; e + (U - 1) * T < per; e += U * T) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) __builtin_nontemporal_store(x, &dst[e + u * T]);
+  }
+  for (; e < per; e += T) __builtin_nontemporal_store(x, &dst[e]);
+}
+// consecutive pieces of PER float4 (16 KB row = 1008, 4 KB tile = 256), each XCD owning one contiguous eighth of them
+template <int PER>
+__global__ __launch_bounds__(256) void store_piece_xcd_kernel(f32x4 *out, unsigned npieces, float v) {
+  const unsigned grp = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const unsigned q = npieces >> 3, r = npieces & 7;
+  const unsigned piece = ((grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q) + slot;
+  f32x4 *dst = out + (long long)piece * PER;
+  f32x4 x = (f32x4)(v);
+  for (int e = threadIdx.x; e < PER; e += 256) __builtin_nontemporal_store(x, &dst[e]);
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 template <class F>
 static float time_ms(F f, int iters) {
@@ -101,6 +127,16 @@ int main() {
 #define PACED(T, U) ms = time_ms([&] { hipLaunchKernelGGL((store_crop_paced_kernel<T, U>), dim3(n), dim3(T), 0, 0, out, 1.f); }, 30); \
   printf("T%-4d paced every %d stores            %8.2f us  %7.1f GB/s\n", T, U, ms * 1e3, bytes / ms / 1e6);
   PACED(256, 1) PACED(256, 2) PACED(256, 4) PACED(256, 8) PACED(1024, 1) PACED(1024, 2) PACED(64, 1) PACED(64, 4)
+  ms = time_ms([&] { hipLaunchKernelGGL((store_crop_xcd_kernel<256, 4>), dim3(n), dim3(256), 0, 0, out, n, 1.f); }, 30);
+  printf("box pattern, XCD-chunked box ranges     %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_crop_kernel<256, 4>), dim3(n), dim3(256), 0, 0, out, 1.f); }, 30);
+  printf("box pattern, box = blockIdx             %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_piece_xcd_kernel<1008>), dim3(n * 7), dim3(256), 0, 0, out, (unsigned)(n * 7), 1.f); }, 30);
+  printf("16 KB rows, XCD-chunked ranges          %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_piece_xcd_kernel<256>), dim3((unsigned)(n4 / 256)), dim3(256), 0, 0, out, (unsigned)(n4 / 256), 1.f); }, 30);
+  printf("4 KB tiles, XCD-chunked ranges          %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
+  ms = time_ms([&] { hipLaunchKernelGGL((store_piece_xcd_kernel<512>), dim3((unsigned)(n4 / 512)), dim3(256), 0, 0, out, (unsigned)(n4 / 512), 1.f); }, 30);
+  printf("8 KB tiles, XCD-chunked ranges          %8.2f us  %7.1f GB/s\n", ms * 1e3, bytes / ms / 1e6);
 #define CMAP(M) ms = time_ms([&] { hipLaunchKernelGGL((store_chunk_map_kernel<M>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, 0, out, n4, 1.f); }, 30); \
   printf("4 KB chunks, XCD map %d                 %8.2f us  %7.1f GB/s\n", M, ms * 1e3, bytes / ms / 1e6);
   CMAP(0) CMAP(1) CMAP(2) CMAP(3) CMAP(4) CMAP(0)
