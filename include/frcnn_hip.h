@@ -177,6 +177,19 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
                       float *out_deltas, float *out_labels, void *workspace,
                       size_t workspace_bytes, frcnn_stream_t stream);
 
+/* frcnn_rpn_targets without a workspace argument and without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory (code under HIP graph capture, tight serving / feeder loops, harnesses that
+ * forbid hipMalloc).  The scratch (frcnn_rpn_targets_workspace_bytes(B,N,M) bytes: max IoU, both argmaxes, column keys)
+ * lives in a file-scope device array of FRCNN_RPN_TARGETS_STATIC_MAX_BYTES that every GPU the library runs on holds until
+ * the process ends; shapes needing more are FRCNN_EUNSUPPORTED.  All calls on one GPU share that array: calls that
+ * overlap on one GPU (different streams, different threads) race -- serialise them on one stream.  Same results as
+ * frcnn_rpn_targets. */
+#define FRCNN_RPN_TARGETS_STATIC_MAX_BYTES ((size_t)8 << 20) /* covers B=64, N=9216, M=100 (4.8 MB) and B=16, N=35721 */
+int frcnn_rpn_targets_static(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                             const int32_t *rnd_pos, const int32_t *rnd_neg, uint64_t seed, int B, int N,
+                             int M, int total_pos, int total_neg, const float *variances,
+                             float *out_deltas, float *out_labels, frcnn_stream_t stream);
+
 /* models/faster_rcnn.py:195-235 RoIDelta.call (second-stage training targets): RoI x gt IoU (:215), row max /
  * first argmax (:216-217), positives > 0.5 and negatives in (0.1, 0.5) sub-sampled to total_pos / total_neg
  * (:218-221), gathered gt box / label (:222-229), encode / variances (:230), one-hot labels and the per-class

@@ -56,6 +56,8 @@ SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
     "frcnn_rpn_targets_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_rpn_targets": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
                                _vp, _sz, _vp]),
+    "frcnn_rpn_targets_static": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
+                                      _vp]),
     "frcnn_roi_delta_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_roi_delta": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
                              _vp, _sz, _vp]),

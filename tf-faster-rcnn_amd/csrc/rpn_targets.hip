@@ -13,6 +13,8 @@
 // One 1024-thread workgroup per image; the per-anchor inputs (max IoU, random ints) are re-read from
 // global memory in each radix pass (36 KB per image, L2 resident) instead of being held in LDS, which
 // only keeps three N-bit maps.  Latency bound: ~0.3 MB of traffic per image.
+#include <mutex>
+
 #include "block_primitives.hpp"
 
 namespace frcnn {
@@ -330,6 +332,36 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
 static const int kMaxTargetsN = 262144;
 static const int kMaxRoiDeltaR = 4096;
 
+// ---- frcnn_rpn_targets_static: the scratch of frcnn_rpn_targets in a file-scope device array --------------------------
+// For callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc).  Every GPU the
+// library runs on holds its own copy of the array until the process ends.  `scratch` is a host-side stand-in in host code,
+// NOT a device address: its per-device address is looked up once per device with hipGetSymbolAddress (static_scratch)
+// and only that pointer is ever handed to kernels / hipMemsetAsync.
+static const size_t kStaticScratchBytes = FRCNN_RPN_TARGETS_STATIC_MAX_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+static const int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static void *g_scratch_ptr[kMaxDevices];  // per device: the address of that device's copy of `scratch`
+
+// The current device's copy of `scratch` (looked up on the first call on that device, with that device current).
+static int static_scratch(void **out) {
+  int dev = -1;
+  int rc = check_hip(hipGetDevice(&dev), "rpn_targets_static: hipGetDevice");
+  if (rc) return rc;
+  if (dev < 0 || dev >= kMaxDevices) return set_error(FRCNN_EUNSUPPORTED, "rpn_targets_static: device %d beyond %d", dev, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void *ptr = nullptr;
+    rc = check_hip(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)), "rpn_targets_static: hipGetSymbolAddress(scratch)");
+    if (rc) return rc;
+    if (!ptr || !aligned_to(ptr, 256)) return set_error(FRCNN_EHIP, "rpn_targets_static: bad scratch address %p", ptr);
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return FRCNN_OK;
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -398,6 +430,25 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
                      rnd_neg, (unsigned long long)seed, N, M, total_pos, total_neg, variances[0], variances[1],
                      variances[2], variances[3], max_iou, argmax_row, argmax_col, out_deltas, out_labels, cache_keys);
   return check_launch("rpn_targets");
+}
+
+int frcnn_rpn_targets_static(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
+                             const int32_t *rnd_pos, const int32_t *rnd_neg, uint64_t seed, int B, int N,
+                             int M, int total_pos, int total_neg, const float *variances,
+                             float *out_deltas, float *out_labels, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(B >= 0 && N > 0 && M > 0, "rpn_targets_static: bad shape B=%d N=%d M=%d", B, N, M);
+  const size_t need = frcnn_rpn_targets_workspace_bytes(B, N, M);
+  if (need > kStaticScratchBytes)
+    return set_error(FRCNN_EUNSUPPORTED,
+                     "rpn_targets_static: B=%d N=%d M=%d needs %zu bytes of scratch, the static buffer holds %zu "
+                     "(use frcnn_rpn_targets with a caller workspace)", B, N, M, need, kStaticScratchBytes);
+  void *ptr = nullptr;
+  int rc = static_scratch(&ptr);
+  if (rc) return rc;
+  // the shared kernels take the scratch as an argument, exactly as in frcnn_rpn_targets; what must start at zero
+  // (the column keys) is cleared by frcnn_iou_map_reduce on `stream` in every call
+  return frcnn_rpn_targets(anchors, gt_boxes, gt_labels, rnd_pos, rnd_neg, seed, B, N, M, total_pos, total_neg, variances,
+                           out_deltas, out_labels, ptr, kStaticScratchBytes, stream);
 }
 
 size_t frcnn_roi_delta_workspace_bytes(int B, int R, int M) {
