@@ -39,6 +39,12 @@ int frcnn_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char *frcnn_last_error(void);
 
+/* Diagnostic: force one of several equivalent schedules (same results; used by the parity tests to cover all of them).
+ * `name` is one of the FRCNN_* knob names listed in DESIGN.md section 7; is_set == 0 restores the default.  The library
+ * reads the environment variables of the same names once, when it is loaded, and never calls getenv afterwards.  No
+ * counterpart in the reference.  Not for use concurrently with other calls. */
+int frcnn_debug_set_schedule(const char *name, int is_set, int value);
+
 /* ---- anchors ------------------------------------------------------------------------- */
 /* utils/bbox_utils.py:37-57 generate_anchors: broadcast add of the base anchors (A,4)
  * (utils/bbox_utils.py:13-34, computed by the host in fp64/fp32 as the reference does) over the

@@ -24,7 +24,7 @@ def pkg():
     return p
 
 
-def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
+def test_fuzz_roi_bbox_all_schedules(pkg, knobs):
     rng = np.random.default_rng(2024)
     for case in range(360):
         G = int(rng.integers(3, 24))
@@ -34,11 +34,11 @@ def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
         thr = float(rng.choice([0.1, 0.3, 0.5, 0.7, 0.9]))
         B = int(rng.integers(1, 4))
         schedule = ("fused", "bitmask", "unfused")[case % 3]
-        monkeypatch.delenv("FRCNN_ROI_BBOX_UNFUSED", raising=False)
-        monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
+        knobs.delenv("FRCNN_ROI_BBOX_UNFUSED", raising=False)
+        knobs.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
         if schedule == "unfused":
-            monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
-        monkeypatch.setenv("FRCNN_PROPOSAL_THREADS", "256" if (case // 3) % 2 else "1024")  # block size of the fused kernel
+            knobs.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+        knobs.setenv("FRCNN_PROPOSAL_THREADS", "256" if (case // 3) % 2 else "1024")  # block size of the fused kernel
         hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
         hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
         anchors = oracle.generate_anchors(hp)
@@ -50,15 +50,15 @@ def test_fuzz_roi_bbox_all_schedules(pkg, monkeypatch):
         assert_bits(got, want, f"RoIBBox fuzz case {case}: {schedule} B={B} G={G} K={K} R={R} thr={thr}")
 
 
-def test_roi_bbox_minus_inf_scores_all_schedules(pkg, monkeypatch):
+def test_roi_bbox_minus_inf_scores_all_schedules(pkg, knobs):
     """Scores of -inf never pass combined_non_max_suppression's strict `score > -inf`: with more than N - K of them the
     top-K holds dead candidates, which every schedule must skip (and NaN-free ties between them order by index)."""
     rng = np.random.default_rng(99)
     for case, schedule in enumerate(("fused", "bitmask", "unfused") * 3):
-        monkeypatch.delenv("FRCNN_ROI_BBOX_UNFUSED", raising=False)
-        monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
+        knobs.delenv("FRCNN_ROI_BBOX_UNFUSED", raising=False)
+        knobs.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", {"fused": "0", "bitmask": "1", "unfused": "0"}[schedule])
         if schedule == "unfused":
-            monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+            knobs.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
         G, K, R = 12, 1000, (40, 400, 1200)[case // 3]
         hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
         hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R)
@@ -73,7 +73,7 @@ def test_roi_bbox_minus_inf_scores_all_schedules(pkg, monkeypatch):
         assert_bits(got, want, f"RoIBBox -inf scores: {schedule} R={R}")
 
 
-def test_fuzz_roi_pooling(pkg, monkeypatch):
+def test_fuzz_roi_pooling(pkg, knobs):
     rng = np.random.default_rng(7)
     for case in range(240):
         B = int(rng.integers(1, 4))
@@ -81,8 +81,8 @@ def test_fuzz_roi_pooling(pkg, monkeypatch):
         C = int(rng.choice([1, 3, 4, 8, 20, 36, 64, 100, 576]))
         R = int(rng.integers(1, 40))
         ph, pw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
-        monkeypatch.setenv("FRCNN_CROP_SLICE", str(case % 2))
-        monkeypatch.setenv("FRCNN_CROP_ROWS", str((case // 2) % 2))  # (box, output row) workgroups (diagnostic schedule)
+        knobs.setenv("FRCNN_CROP_SLICE", str(case % 2))
+        knobs.setenv("FRCNN_CROP_ROWS", str((case // 2) % 2))  # (box, output row) workgroups (diagnostic schedule)
         fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
         rois = rng.uniform(-0.2, 1.2, (B, R, 4)).astype(np.float32)  # inverted and out-of-image boxes included
         hp = synth.hyper_params(pooling_size=(ph, pw))
@@ -91,14 +91,14 @@ def test_fuzz_roi_pooling(pkg, monkeypatch):
         assert_bits(got, want, f"RoIPooling fuzz case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw})")
 
 
-def test_fuzz_decoder(pkg, monkeypatch):
+def test_fuzz_decoder(pkg, knobs):
     rng = np.random.default_rng(11)
     for case in range(240):
         B, R, L = int(rng.integers(1, 4)), int(rng.integers(1, 400)), int(rng.integers(2, 30))
         T = int(rng.integers(1, 300))
         thr = float(rng.choice([0.05, 0.3, 0.5, 0.8]))
-        monkeypatch.setenv("FRCNN_DECODER_UNFUSED", str(case % 2))
-        monkeypatch.setenv("FRCNN_DECODER_THREADS", "256" if (case // 2) % 2 else "1024")  # block size of the fused kernel
+        knobs.setenv("FRCNN_DECODER_UNFUSED", str(case % 2))
+        knobs.setenv("FRCNN_DECODER_THREADS", "256" if (case // 2) % 2 else "1024")  # block size of the fused kernel
         hp = synth.hyper_params()
         rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
         deltas = rng.normal(0, 0.5, (B, R, L * 4)).astype(np.float32)

@@ -359,9 +359,9 @@ def test_roi_bbox_config2(pkg):
     assert_bits(got, want, "RoIBBox cfg2")
 
 
-def test_roi_bbox_fused_kernel_large_r(pkg, monkeypatch):
+def test_roi_bbox_fused_kernel_large_r(pkg, knobs):
     """The one-workgroup-per-image kernel at a post_nms_topn the bitmask schedule would otherwise take."""
-    monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "0")
+    knobs.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "0")
     got, want = _roi_bbox_case(pkg, 2, 2, 31, 6000, 2000, mode="training")
     assert_bits(got, want, "RoIBBox fused kernel, R=2000")
 
@@ -379,9 +379,9 @@ def test_roi_bbox_stress_shape(pkg):
     assert_bits(got, want, "RoIBBox cfg5")
 
 
-def test_roi_bbox_unfused_path(pkg, monkeypatch):
+def test_roi_bbox_unfused_path(pkg, knobs):
     """The generic sort -> NMS pipeline behind frcnn_roi_bbox (taken when the fused kernel's LDS budget is exceeded)."""
-    monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+    knobs.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
     got, want = _roi_bbox_case(pkg, 7, 2, 16, 2304, 1500, mode="training")
     assert_bits(got, want, "RoIBBox unfused large R")
     got, want = _roi_bbox_case(pkg, 5, 4, 32, 6000, 300)
@@ -390,10 +390,10 @@ def test_roi_bbox_unfused_path(pkg, monkeypatch):
     assert_bits(got, want, "RoIBBox unfused cfg5")
 
 
-def test_roi_bbox_bitmask_path(pkg, monkeypatch):
+def test_roi_bbox_bitmask_path(pkg, knobs):
     """The whole-chip bitmask schedule (taken for post_nms_topn >= 512), forced on every shape: one and several phases,
     early finish, exhausted candidates, ties, K not a multiple of 64, R larger than K."""
-    monkeypatch.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "1")
+    knobs.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "1")
     for args, kw in (((10, 2, 8, 64, 16), {}), ((11, 2, 16, 2304, 300), {}), ((12, 4, 32, 6000, 300), {}),
                      ((13, 3, 31, 6000, 2000), dict(mode="training")), ((14, 2, 16, 1000, 100), dict(unique=False, thr=0.5)),
                      ((15, 2, 63, 12000, 1500), dict(mode="training")), ((16, 2, 8, 570, 600), {}),
@@ -437,14 +437,14 @@ def test_roi_pooling(pkg, B, G, C, R):
     assert_bits(got, want, "RoIPooling")
 
 
-def test_roi_pooling_channel_slice_kernel(pkg, monkeypatch):
+def test_roi_pooling_channel_slice_kernel(pkg, knobs):
     """The kernel used for feature maps larger than an XCD's L2 (each XCD owns an eighth of the channels): forced on small
     shapes (incl. a depth that leaves the last slices empty), and taken by itself on a 63x63x576 map."""
-    monkeypatch.setenv("FRCNN_CROP_SLICE", "1")
+    knobs.setenv("FRCNN_CROP_SLICE", "1")
     test_roi_pooling(pkg, 2, 8, 8, 16)
     test_roi_pooling(pkg, 2, 31, 512, 64)
     test_roi_pooling(pkg, 1, 9, 20, 33)
-    monkeypatch.delenv("FRCNN_CROP_SLICE")
+    knobs.delenv("FRCNN_CROP_SLICE")
     test_roi_pooling(pkg, 1, 63, 576, 40)
 
 
@@ -478,9 +478,9 @@ def test_decoder(pkg, B, R, L):
         assert_bits(g, w, f"Decoder {name}")
 
 
-def test_decoder_unfused_path(pkg, monkeypatch):
+def test_decoder_unfused_path(pkg, knobs):
     """The generic sort -> NMS -> merge pipeline behind frcnn_decoder (taken when the fused kernel does not fit)."""
-    monkeypatch.setenv("FRCNN_DECODER_UNFUSED", "1")
+    knobs.setenv("FRCNN_DECODER_UNFUSED", "1")
     test_decoder(pkg, 16, 300, 21)
     test_decoder_unnormalised_scores(pkg)
 
@@ -517,6 +517,26 @@ def test_decoder_unnormalised_scores(pkg):
     want = oracle.decoder(rois, deltas, probs, hp["variances"], L, 50, 0.35)
     for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
         assert_bits(g, w, f"Decoder un-normalised {name}")
+
+
+@pytest.mark.parametrize("unfused", [False, True])
+def test_decoder_negative_score_threshold(pkg, knobs, unfused):
+    """score_threshold < 0: the rows the reference zeroes (background argmax, models/faster_rcnn.py:83) pass `0 > thr`
+    and are candidates with score 0 -- on both schedules (the fused kernel hands such thresholds to the generic path)."""
+    if unfused:
+        knobs.setenv("FRCNN_DECODER_UNFUSED", "1")
+    hp = synth.hyper_params()
+    B, R, L = 2, 40, 5
+    rng = np.random.default_rng(33)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    deltas, probs = synth.head_outputs(3, B, R, L)
+    for T in (200, 30):
+        layer = pkg.faster_rcnn.Decoder(hp["variances"], L, max_total_size=T, score_threshold=-0.25)
+        got = layer([dev(rois), dev(deltas), dev(probs)])
+        want = oracle.decoder(rois, deltas, probs, hp["variances"], L, T, -0.25)
+        assert ((want[2] > 0) & (want[2] < 0.5)).any()  # candidates the default threshold would have dropped
+        for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
+            assert_bits(g, w, f"Decoder thr<0 T={T} {name}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -857,8 +877,83 @@ def test_pipeline_grouped_launches_at_config2_size(pkg):
         assert int((got["roi_bboxes"].abs().sum(-1) > 0).sum()) > B * R // 2  # real proposals, not padding
 
 
+def _small_pipeline(pkg, depth=2, crop_group=1, B=2, G=12, C=16, L=4, R=24):
+    from tf_faster_rcnn_amd import pipeline
+
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=600, test_nms_topn=R, total_labels=L)
+    anchors = oracle.generate_anchors(hp)
+    layers = (pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp), pkg.faster_rcnn.RoIPooling(hp),
+              pkg.faster_rcnn.Decoder(hp["variances"], L))
+    pipe = pipeline.RoIPathPipeline(*layers, depth=depth, crop_group=crop_group)
+    batches = []
+    for seed in range(4):
+        deltas, scores = synth.rpn_outputs(90 + seed, B, G)
+        hd, hpb = synth.head_outputs(90 + seed, B, R, L)
+        batches.append(tuple(dev(a) for a in (deltas, scores, synth.feature_map(90 + seed, B, G, C), hd, hpb)))
+    return pipeline, layers, pipe, batches
+
+
+@pytest.mark.parametrize("callable_heads", [False, True])
+@pytest.mark.parametrize("crop_group", [1, 2])
+def test_pipeline_head_outputs_that_need_a_conversion(pkg, callable_heads, crop_group):
+    """Head outputs that are not contiguous fp32 device tensors (fp64, a transposed view, host memory): the copy that
+    normalises them is ordered before the Decoder stage on whichever stream it runs (tuple heads: the caller's stream,
+    before the input event; callable heads: the pooling stream).  Results as the sequential layers on the converted
+    values.  A large spin kernel in front makes a missing ordering visible."""
+    pipeline, layers, pipe, batches = _small_pipeline(pkg, depth=4, crop_group=crop_group)
+    L = 4
+    for i, b in enumerate(batches):
+        hd, hp_ = b[3], b[4]
+        awkward = [
+            (hd.double(), hp_.double()),                                                      # dtype conversion
+            (hd.reshape(hd.shape[0], hd.shape[1], L, 4).permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2), # non-contiguous view
+             hp_.transpose(1, 2).contiguous().transpose(1, 2)),
+            (hd.cpu(), hp_.cpu()),                                                            # host tensors
+            (hd.half().float().half(), hp_),                                                  # fp16 (values change: compared below)
+        ][i]
+        torch.cuda.synchronize()  # the awkward tensors exist; what is under test is the ordering of their CONVERSION
+        if callable_heads:
+            heads = lambda pooled, rois, a=awkward: (torch.cuda._sleep(2_000_000), a)[1]  # noqa: E731
+        else:
+            torch.cuda._sleep(2_000_000)
+            heads = awkward
+        pipe.submit(b[0], b[1], b[2], heads)
+    pipe.synchronize()
+    for i, b in enumerate(batches):
+        got = pipe.result(i)
+        hd = b[3].half().float() if i == 3 else b[3]
+        seq = pipeline.run_sequential(*layers, (b[0], b[1], b[2], hd, b[4]))
+        for name in ("roi_bboxes", "roi_pooled", "bboxes", "labels", "scores"):
+            assert torch.equal(got[name].view(torch.int32), seq[name].view(torch.int32)), f"batch {i} {name}"
+
+
+def test_pipeline_failed_group_is_reported_not_returned_stale(pkg):
+    """A head callable that returns the wrong shape: flush raises, result() of that batch raises too (never the slot's
+    previous contents), and the pipeline keeps working for later batches."""
+    pipeline, layers, pipe, batches = _small_pipeline(pkg, depth=2, crop_group=1)
+    b = batches[0]
+    t0 = pipe.submit(b[0], b[1], b[2], (b[3], b[4]))
+    pipe.result(t0)
+    t1 = pipe.submit(b[0], b[1], b[2], (b[3], b[4]))
+    with pytest.raises(ValueError):
+        pipe.submit(b[0], b[1], b[2], lambda pooled, rois: (b[3][:, :5], b[4]))  # ticket 2 reuses slot 0
+    with pytest.raises(RuntimeError):
+        pipe.result(2)
+    pipe.result(t1)
+    with pytest.raises(ValueError):  # tuple heads are checked before anything is touched: no ticket is consumed
+        pipe.submit(b[0], b[1], b[2], (b[3][:, :5], b[4]))
+    c = batches[1]
+    t3 = pipe.submit(c[0], c[1], c[2], (c[3], c[4]))
+    assert t3 == 3
+    got = pipe.result(t3)
+    seq = pipeline.run_sequential(*layers, c)
+    for name in ("roi_bboxes", "roi_pooled", "bboxes", "labels", "scores"):
+        assert torch.equal(got[name].view(torch.int32), seq[name].view(torch.int32)), name
+
+
 @pytest.mark.parametrize("schedule", ["unfused", "bitmask"])
-def test_pipeline_groups_on_schedules_without_a_grouped_form(pkg, monkeypatch, schedule):
+def test_pipeline_groups_on_schedules_without_a_grouped_form(pkg, knobs, schedule):
     """crop_group > 1 where frcnn_roi_bbox_multi / frcnn_decoder_multi have no grouped launch (the generic sort -> NMS
     pipelines, the whole-chip bitmask NMS): they run one call per batch on the shared workspace; results as sequential."""
     from tf_faster_rcnn_amd import pipeline
@@ -866,8 +961,8 @@ def test_pipeline_groups_on_schedules_without_a_grouped_form(pkg, monkeypatch, s
     B, G, C, L = 2, 12, 16, 4
     R = 24 if schedule == "unfused" else 600
     if schedule == "unfused":
-        monkeypatch.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
-        monkeypatch.setenv("FRCNN_DECODER_UNFUSED", "1")
+        knobs.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
+        knobs.setenv("FRCNN_DECODER_UNFUSED", "1")
     hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
     hp.update(feature_map_shape=G, pre_nms_topn=1000, test_nms_topn=R, total_labels=L)
     anchors = oracle.generate_anchors(hp)

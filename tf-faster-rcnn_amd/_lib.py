@@ -34,6 +34,7 @@ _sz = ctypes.c_size_t
 SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
     "frcnn_version": (_i, []),
     "frcnn_last_error": (ctypes.c_char_p, []),
+    "frcnn_debug_set_schedule": (_i, [ctypes.c_char_p, _i, _i]),
     "frcnn_generate_anchors": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
     "frcnn_decode_boxes": (_i, [_vp, _i, _vp, _c_float_p, _i64, _i64, _vp, _vp]),
     "frcnn_encode_boxes": (_i, [_vp, _i, _vp, _c_float_p, _i64, _i64, _vp, _vp]),
@@ -84,6 +85,11 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_schedule(name: str, value: Optional[int]) -> None:
+    """Diagnostic: force a schedule knob (``FRCNN_*`` name); ``None`` restores the default."""
+    check(lib().frcnn_debug_set_schedule(name.encode(), 0 if value is None else 1, 0 if value is None else int(value)))
+
+
 class UnsupportedSizeError(RuntimeError):
     """A size beyond what the kernels are built for (FRCNN_EUNSUPPORTED)."""
 
@@ -120,6 +126,25 @@ def device_tensor(x: Any, dtype: torch.dtype, device: Optional[torch.device] = N
     if x.dtype != dtype:
         x = x.to(dtype)
     return x.contiguous()
+
+
+class _NoGuard:
+    def __enter__(self) -> None:
+        return None
+
+    def __exit__(self, *exc: Any) -> bool:
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device: torch.device):
+    """Context in which ``device`` is the current HIP device: the library's launches and ``hipFuncSetAttribute`` calls
+    act on the current device, not on the device of the pointers they are given.  Free when it already is current."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

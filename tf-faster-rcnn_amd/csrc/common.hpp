@@ -16,11 +16,34 @@ namespace frcnn {
 int set_error(int code, const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 int check_launch(const char *what);
+// Raise `kernel`'s dynamic-LDS limit to at least `bytes` on the current device.  hipFuncSetAttribute is called only when
+// the limit this library last set for (kernel, device) is below `bytes`: nothing per launch in the steady state.
+int ensure_dynamic_lds(const void *kernel, size_t bytes, const char *what);
 
 #define FRCNN_REQUIRE(cond, ...)                                  \
   do {                                                            \
     if (!(cond)) return ::frcnn::set_error(FRCNN_EINVAL, __VA_ARGS__); \
   } while (0)
+
+// ---- schedule overrides (api.hip) ------------------------------------------------------------
+// Diagnostic / test knobs that force one of several equivalent schedules.  Each is read ONCE from the environment variable
+// of the same name when the library is loaded and can be changed afterwards only through frcnn_debug_set_schedule():
+// no entry point calls getenv.
+enum Knob {
+  kKnobCropSlice,        // FRCNN_CROP_SLICE            0|1
+  kKnobCropRows,         // FRCNN_CROP_ROWS             0|1
+  kKnobDecoderThreads,   // FRCNN_DECODER_THREADS       256|1024
+  kKnobRoiBboxUnfused,   // FRCNN_ROI_BBOX_UNFUSED      1
+  kKnobDecoderUnfused,   // FRCNN_DECODER_UNFUSED       1
+  kKnobBitmaskMinR,      // FRCNN_ROI_BBOX_BITMASK_MIN_R n (0 = never)
+  kKnobProposalChunk,    // FRCNN_PROPOSAL_CHUNK        64|128|256
+  kKnobProposalThreads,  // FRCNN_PROPOSAL_THREADS      256|1024
+  kKnobIouTile,          // FRCNN_IOU_TILE              elements per lane of the flat IoU-map kernel
+  kKnobIouMapFlat,       // FRCNN_IOU_MAP_FLAT          1
+  kKnobCount
+};
+bool knob_set(Knob k);
+int knob(Knob k, int unset_value);  // the knob's value, or unset_value
 
 static inline bool aligned_to(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -330,8 +330,7 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   // (e.g. 63x63x576 = 9.1 MB) is read through the channel-slice kernel instead, each XCD holding one eighth of it
   // (measured: 179 against 232 us at config 5; 23 % slower than the box kernel at config 2, whose images fit).
   // FRCNN_CROP_SLICE=0|1 forces the choice (diagnostic).
-  const char *force_env = getenv("FRCNN_CROP_SLICE");
-  const int force_slice = force_env ? atoi(force_env) : -1;
+  const int force_slice = knob(kKnobCropSlice, -1);
   bool use_slice = false;
   if (vec4 && aligned_to(boxes, 16) && (long long)n * 8 < (1ll << 31) && (long long)crop_h * crop_w * C * 4 < (1ll << 32))
     use_slice = force_slice >= 0 ? force_slice != 0 : (double)H * W * C * 4 > 4.0 * 1024 * 1024;
@@ -342,9 +341,8 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
     return check_launch("crop_and_resize");
   }
   // FRCNN_CROP_ROWS=0|1 forces the (box) / (box, output row) decomposition (diagnostic).
-  const char *rows_env = getenv("FRCNN_CROP_ROWS");
   const bool rows_fit = (long long)n * crop_h < (1ll << 31);
-  const bool use_rows = vec4 && rows_fit && (rows_env ? atoi(rows_env) != 0 : false);
+  const bool use_rows = vec4 && rows_fit && (knob(kKnobCropRows, 0) != 0);
   CropGroups gr = {};
   gr.image[0] = image;
   gr.boxes[0] = boxes;
@@ -371,7 +369,7 @@ extern "C" int frcnn_crop_and_resize_multi(const float *const *images, const flo
   FRCNN_REQUIRE(boxes_per_image > 0, "crop_and_resize_multi: boxes_per_image must be positive");
   FRCNN_REQUIRE(n >= 0, "crop_and_resize_multi: negative box count");
   bool one_launch = groups > 1 && n > 0 && (C % 4 == 0) && (long long)n * groups < (1ll << 28) &&
-                    !((double)H * W * C * 4 > 4.0 * 1024 * 1024) && !getenv("FRCNN_CROP_SLICE") && !getenv("FRCNN_CROP_ROWS");
+                    !((double)H * W * C * 4 > 4.0 * 1024 * 1024) && !knob_set(kKnobCropSlice) && !knob_set(kKnobCropRows);
   for (int g = 0; g < groups; ++g) {
     FRCNN_REQUIRE(images[g] && boxes[g] && outs[g], "crop_and_resize_multi: null pointer in triple %d", g);
     one_launch = one_launch && aligned_to(images[g], 16) && aligned_to(outs[g], 16);

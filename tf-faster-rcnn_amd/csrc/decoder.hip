@@ -444,9 +444,12 @@ int launch_decoder(const float *const *rois, const float *const *deltas, const f
                    float *const *out_boxes, float *const *out_labels, float *const *out_scores, int *const *out_valid,
                    hipStream_t stream, bool small_footprint, bool *handled) {
   *handled = false;
-  if (const char *e = getenv("FRCNN_DECODER_THREADS")) small_footprint = atoi(e) == 256;  // diagnostic override
+  if (knob_set(kKnobDecoderThreads)) small_footprint = knob(kKnobDecoderThreads, 0) == 256;  // diagnostic override
   const int nt = small_footprint ? 256 : 1024;
   if (groups < 1 || groups > kDecoderGroups) return FRCNN_OK;
+  // Rows whose argmax is background are ZEROED by the reference (models/faster_rcnn.py:83), not dropped: with a negative
+  // threshold their 0 scores are candidates (0 > thr).  The fused kernel drops them, so it only takes thresholds >= 0.
+  if (!(score_thr >= 0.0f)) return FRCNN_OK;
   if (L > kDecMaxClasses || R >= (1 << 24) || R <= 0 || max_total <= 0) return FRCNN_OK;
   const long long rl = (long long)R * L;
   if (rl > 65535) return FRCNN_OK;
@@ -481,9 +484,7 @@ int launch_decoder(const float *const *rois, const float *const *deltas, const f
   p.iou = make_iou_thr(iou_thr);
   auto kern = small_footprint ? decoder_kernel<256> : decoder_kernel<1024>;
   if (lds > 48 * 1024) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                       "decoder: hipFuncSetAttribute");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "decoder: hipFuncSetAttribute");
     if (rc) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(B * groups)), dim3(nt), lds, stream, p, Vcap, Rpc4, nms_waves);

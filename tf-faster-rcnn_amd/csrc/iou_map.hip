@@ -349,14 +349,13 @@ int frcnn_iou_map(const float *bboxes, int bboxes_batched, const float *gt_boxes
   FRCNN_REQUIRE(total < (1ll << 31) - 65536, "iou_map: N*M per image too large");
   // Small tiles written in address order stream best (tools/crop_bench.hip: 4-16 KB per workgroup); 8 elements per
   // lane amortise the gt staging.  FRCNN_IOU_TILE overrides the per-lane count (diagnostic).
-  static const int per_lane = [] { const char *e = getenv("FRCNN_IOU_TILE"); int v = e ? atoi(e) : 8; return v > 0 ? v : 8; }();
+  const int per_lane = knob(kKnobIouTile, 8) > 0 ? knob(kKnobIouTile, 8) : 8;
   const int per_block = 256 * per_lane;
   const long long tiles = (total + per_block - 1) / per_block;
   dim3 grid((unsigned)tiles, (unsigned)B), block(256);
   const long long stride = bboxes_batched ? (long long)N * 4 : 0;
   if (vec4) {
-    static const bool flat = [] { const char *e = getenv("FRCNN_IOU_MAP_FLAT"); return e && atoi(e) != 0; }();  // diagnostic A/B
-    if (flat)
+    if (knob(kKnobIouMapFlat, 0) != 0)  // diagnostic A/B
       hipLaunchKernelGGL(iou_map_kernel<true>, grid, block, lds_bytes, (hipStream_t)stream, bboxes, stride, gt_boxes, N, M,
                          out, per_block);
     else

@@ -259,7 +259,7 @@ static int launch_nms_t(const NmsParams &p, long long S, int Rc, hipStream_t str
     return set_error(FRCNN_EUNSUPPORTED, "nms: %d boxes kept per class exceeds the in-LDS kept-list capacity %d", p.R, kMaxKept);
   auto kern = nms_kernel<NT, CH>;
   if (lds > 48 * 1024) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "nms: hipFuncSetAttribute");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "nms: hipFuncSetAttribute");
     if (rc) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)S), dim3(NT), lds, stream, p, Rc);
@@ -438,8 +438,7 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
   {
     // One fused kernel per image (proposal.hip) whenever its LDS budget allows; FRCNN_ROI_BBOX_UNFUSED=1
     // forces the generic sort -> NMS pipeline (used by the parity tests to cover both).
-    const char *force = getenv("FRCNN_ROI_BBOX_UNFUSED");
-    if (!(force && force[0] == '1')) {
+    if (knob(kKnobRoiBboxUnfused, 0) != 1) {
       bool handled = false;
       const int Rn = R < K ? R : K;
       // large post_nms_topn (training): the pair tests go to the whole chip (nms_bitmask.hip)
@@ -494,8 +493,7 @@ int frcnn_roi_bbox_multi(const float *const *deltas, const float *const *scores,
   FRCNN_REQUIRE(ok, "roi_bbox_multi: box pointers must be 16-byte aligned");
   if (B == 0) return FRCNN_OK;
   const int Rn = R < K ? R : K;
-  const char *force = getenv("FRCNN_ROI_BBOX_UNFUSED");
-  if (groups > 1 && !(force && force[0] == '1') && !roi_bbox_bitmask_applies(B, K, Rn)) {
+  if (groups > 1 && knob(kKnobRoiBboxUnfused, 0) != 1 && !roi_bbox_bitmask_applies(B, K, Rn)) {
     bool handled = false;
     int rc = launch_proposal(deltas, scores, groups, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes, nullptr,
                              nullptr, (hipStream_t)stream, false, &handled);
@@ -528,8 +526,7 @@ int frcnn_decoder(const float *rois, const float *deltas, const float *probs,
   {
     // One fused kernel per image (decoder.hip) whenever its LDS budget allows; FRCNN_DECODER_UNFUSED=1 forces
     // the generic sort -> NMS -> merge pipeline (used by the parity tests to cover both).
-    const char *force = getenv("FRCNN_DECODER_UNFUSED");
-    if (!(force && force[0] == '1')) {
+    if (knob(kKnobDecoderUnfused, 0) != 1) {
       bool handled = false;
       int rc = launch_decoder(&rois, &deltas, &probs, 1, variances, B, R, L, max_total, score_threshold, iou_threshold,
                               &out_boxes, &out_labels, &out_scores, &out_valid, (hipStream_t)stream, false, &handled);
@@ -575,8 +572,7 @@ int frcnn_decoder_multi(const float *const *rois, const float *const *deltas, co
   }
   FRCNN_REQUIRE(ok, "decoder_multi: box pointers must be 16-byte aligned");
   if (B == 0) return FRCNN_OK;
-  const char *force = getenv("FRCNN_DECODER_UNFUSED");
-  if (groups > 1 && !(force && force[0] == '1')) {
+  if (groups > 1 && knob(kKnobDecoderUnfused, 0) != 1) {
     bool handled = false;
     int rc = launch_decoder(rois, deltas, probs, groups, variances, B, R, L, max_total, score_threshold, iou_threshold,
                             out_boxes, out_labels, out_scores, nullptr, (hipStream_t)stream, false, &handled);

@@ -342,8 +342,7 @@ static BitmaskWorkspace carve_bitmask(void *ws, int B, int K, int R) {
 
 // R_nms at or above which frcnn_roi_bbox takes this path (FRCNN_ROI_BBOX_BITMASK_MIN_R overrides; 0 disables).
 int roi_bbox_bitmask_min_r() {
-  if (const char *e = getenv("FRCNN_ROI_BBOX_BITMASK_MIN_R")) return atoi(e);
-  return 512;  // measured crossover at B=16, K=6000: R=500 149 us either way; R=700 302 (fused) / 153; R=1500 1653 / 368
+  return knob(kKnobBitmaskMinR, 512);  // measured crossover at B=16, K=6000: R=500 149 us either way; R=700 302 (fused) / 153; R=1500 1653 / 368
 }
 
 bool roi_bbox_bitmask_applies(int B, int K, int R_nms) {
@@ -403,8 +402,7 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   const size_t lds = (size_t)p.nb * 8 + (size_t)((R_nms + 1) & ~1) * 4 + (size_t)kBandBlocks * 64 * 8;
   auto scan = bm_scan_kernel;
   if (lds > 48 * 1024) {
-    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                   "roi_bbox: hipFuncSetAttribute");
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(scan), lds, "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
   }
   for (int cb0 = 0; cb0 < p.nb; cb0 += kBandBlocks) {

@@ -51,9 +51,10 @@ static inline size_t proposal_lds_bytes(int Rc, int S) {
 // cache_keys: the image's N sort keys are held in LDS (after the other arrays) so that the radix-select
 // passes and the compaction read LDS instead of re-reading the scores through L2.
 // NT = 1024: the whole CU works on the image (lowest latency; what the layers use when called one after the other).
-// NT = 256 ("small footprint", frcnn_roi_bbox's FRCNN_SCHED_SMALL flag): four waves and at most 128 VGPRs, the shape of a
+// NT = 256 ("small footprint", diagnostic knob FRCNN_PROPOSAL_THREADS=256): four waves and at most 128 VGPRs, the shape of a
 // crop_and_resize workgroup, so that the workgroup becomes resident beside the crop kernel's as soon as one of those
-// retires instead of waiting for a crop launch's tail (tools/coresidency_probe.hip) -- the stage pipeline's choice.
+// retires instead of waiting for a crop launch's tail (tools/coresidency_probe.hip).  Measured slower end to end in the
+// stage pipeline, so every entry point, the *_multi ones included, launches NT = 1024.
 template <int CH, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
 void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
@@ -234,9 +235,7 @@ static int launch_proposal_t(ProposalParams &p, int B, int Rc, int S, hipStream_
   if (cache_keys) lds += (size_t)p.N * 4;
   auto kern = proposal_kernel<CH, NT>;
   if (lds > 48 * 1024) {
-    int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                       "roi_bbox: hipFuncSetAttribute");
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NT), lds, stream, p, Rc, S, cache_keys);
@@ -282,9 +281,8 @@ int launch_proposal(const float *const *deltas, const float *const *scores, int 
   p.iou = make_iou_thr(iou_thr);
   p.score_thr = -__builtin_huge_valf();
   // chunk width: tuning knob (FRCNN_PROPOSAL_CHUNK = 64 | 128 | 256), default 128
-  int ch = 128;
-  if (const char *e = getenv("FRCNN_PROPOSAL_CHUNK")) ch = atoi(e);
-  if (const char *e = getenv("FRCNN_PROPOSAL_THREADS")) small_footprint = atoi(e) == 256;  // diagnostic override
+  const int ch = knob(kKnobProposalChunk, 128);
+  if (knob_set(kKnobProposalThreads)) small_footprint = knob(kKnobProposalThreads, 0) == 256;  // diagnostic override
   if (small_footprint) {
     if (ch == 64) return launch_proposal_t<64, 256>(p, B, Rc, S, stream, handled);
     return launch_proposal_t<128, 256>(p, B, Rc, S, stream, handled);

@@ -422,8 +422,7 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
   if (cache_keys) lds += (size_t)N * 4;
   auto kern = rpn_targets_kernel;
   if (lds > 48 * 1024) {
-    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                   "rpn_targets: hipFuncSetAttribute");
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "rpn_targets: hipFuncSetAttribute");
     if (rc) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTNT), lds, (hipStream_t)stream, anchors, gt_boxes, gt_labels, rnd_pos,
@@ -483,8 +482,7 @@ int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_
   const size_t lds = (size_t)((2 * words + 3) & ~3) * 4 + (size_t)R * 24;
   auto kern = roi_delta_kernel;
   if (lds > 48 * 1024) {
-    rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                   "roi_delta: hipFuncSetAttribute");
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "roi_delta: hipFuncSetAttribute");
     if (rc) return rc;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTNT), lds, (hipStream_t)stream, rois, gt_boxes, gt_labels, rnd_pos, rnd_neg,

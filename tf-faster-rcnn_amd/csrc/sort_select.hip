@@ -164,9 +164,7 @@ int launch_sort_select(const ScoreSource &src, int B, int c, int n, int K, bool 
   if (idx16) {
     auto kern = sort_select_kernel<uint16_t>;
     if (lds > 48 * 1024) {
-      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                         "sort_select: hipFuncSetAttribute");
+      int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "sort_select: hipFuncSetAttribute");
       if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, src, c, n, keff, use_thr ? 1 : 0, thr, slots, do_select,
@@ -174,9 +172,7 @@ int launch_sort_select(const ScoreSource &src, int B, int c, int n, int K, bool 
   } else {
     auto kern = sort_select_kernel<uint32_t>;
     if (lds > 48 * 1024) {
-      int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                         "sort_select: hipFuncSetAttribute");
+      int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "sort_select: hipFuncSetAttribute");
       if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, src, c, n, keff, use_thr ? 1 : 0, thr, slots, do_select,

@@ -102,9 +102,10 @@ class Decoder(Layer):
         scores = torch.empty((B, T), dtype=torch.float32, device=device)
         lib = _lib.lib()
         ws = _lib.workspace(lib.frcnn_decoder_workspace_bytes(B, R, L, T), device)
-        _lib.check(lib.frcnn_decoder(_lib.ptr(rois), _lib.ptr(deltas), _lib.ptr(probs), _lib.float4(self.variances),
-                                     B, R, L, T, float(self.score_threshold), 0.5, _lib.ptr(boxes), _lib.ptr(labels),
-                                     _lib.ptr(scores), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
+        with _lib.on_device(device):
+            _lib.check(lib.frcnn_decoder(_lib.ptr(rois), _lib.ptr(deltas), _lib.ptr(probs), _lib.float4(self.variances),
+                                         B, R, L, T, float(self.score_threshold), 0.5, _lib.ptr(boxes), _lib.ptr(labels),
+                                         _lib.ptr(scores), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
         return boxes, labels, scores
 
 
@@ -151,10 +152,11 @@ class RoIBBox(Layer):
         out = torch.empty((B, post_nms_topn, 4), dtype=torch.float32, device=device)
         lib = _lib.lib()
         ws = _lib.workspace(lib.frcnn_roi_bbox_workspace_bytes(B, total_anchors, pre_nms_topn, post_nms_topn), device)
-        _lib.check(lib.frcnn_roi_bbox(_lib.ptr(deltas), _lib.ptr(scores), _lib.ptr(self.anchors),
-                                      _lib.float4(hp["variances"]), B, total_anchors, pre_nms_topn, post_nms_topn,
-                                      nms_iou_threshold, _lib.ptr(out), None, None, _lib.ptr(ws), ws.numel(),
-                                      _lib.stream_ptr(device)))
+        with _lib.on_device(device):
+            _lib.check(lib.frcnn_roi_bbox(_lib.ptr(deltas), _lib.ptr(scores), _lib.ptr(self.anchors),
+                                          _lib.float4(hp["variances"]), B, total_anchors, pre_nms_topn, post_nms_topn,
+                                          nms_iou_threshold, _lib.ptr(out), None, None, _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_ptr(device)))
         return out
 
 
@@ -220,10 +222,11 @@ class RoIDelta(Layer):
         labels = torch.empty((B, R, L), dtype=torch.float32, device=device)
         lib = _lib.lib()
         ws = _lib.workspace(lib.frcnn_roi_delta_workspace_bytes(B, R, M), device)
-        _lib.check(lib.frcnn_roi_delta(_lib.ptr(rois), _lib.ptr(gt), _lib.ptr(lab), _lib.ptr(rp), _lib.ptr(rn),
-                                       int(seed) & 0xFFFFFFFFFFFFFFFF, B, R, M, L, total_pos, total_neg,
-                                       _lib.float4(hp["variances"]), _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws),
-                                       ws.numel(), _lib.stream_ptr(device)))
+        with _lib.on_device(device):
+            _lib.check(lib.frcnn_roi_delta(_lib.ptr(rois), _lib.ptr(gt), _lib.ptr(lab), _lib.ptr(rp), _lib.ptr(rn),
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, B, R, M, L, total_pos, total_neg,
+                                           _lib.float4(hp["variances"]), _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws),
+                                           ws.numel(), _lib.stream_ptr(device)))
         return deltas, labels
 
 
@@ -263,6 +266,7 @@ class RoIPooling(Layer):
         R = rois.shape[1]
         out = torch.empty((B, R, ph, pw, C), dtype=torch.float32, device=device)
         if B * R:
-            _lib.check(_lib.lib().frcnn_crop_and_resize(_lib.ptr(fm), B, H, W, C, _lib.ptr(rois), None, B * R, R, ph, pw,
-                                                        0.0, _lib.ptr(out), _lib.stream_ptr(device)))
+            with _lib.on_device(device):
+                _lib.check(_lib.lib().frcnn_crop_and_resize(_lib.ptr(fm), B, H, W, C, _lib.ptr(rois), None, B * R, R, ph, pw,
+                                                            0.0, _lib.ptr(out), _lib.stream_ptr(device)))
         return out

@@ -97,7 +97,8 @@ def _stage_streams(device: torch.device, want: int = 3) -> List[torch.cuda.Strea
 
 
 class _Slot:
-    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy", "pending", "wait_in", "small", "h_small", "host")
+    __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy", "pending", "wait_in", "small", "h_small", "host",
+                 "failed", "ticket")
 
     def __init__(self) -> None:
         self.rois = self.pooled = self.boxes = self.labels = self.scores = None
@@ -108,6 +109,8 @@ class _Slot:
         self.wait_in = False      # the proposal stage must wait for an event recorded on the caller's stream
         self.small = self.h_small = None  # the small outputs packed in one buffer (device) and its pinned host copy
         self.host: Any = None             # host views of rois / boxes / labels / scores (host_outputs=True)
+        self.failed: Optional[BaseException] = None  # the error that kept this slot's batch from being enqueued
+        self.ticket = -1
 
 
 class RoIPathPipeline:
@@ -218,6 +221,12 @@ class RoIPathPipeline:
         scores = _lib.device_tensor(rpn_labels, torch.float32, dev)
         fm = _lib.device_tensor(feature_map, torch.float32, dev)
         self._prepare(deltas, scores, fm)
+        converted = any(a is not b for a, b in ((deltas, rpn_bbox_deltas), (scores, rpn_labels), (fm, feature_map)))
+        if not callable(heads):
+            # head outputs handed over as tensors: normalise them HERE, on the caller's stream and before the input event
+            # is recorded, so that the Decoder stage is ordered after any dtype / layout / host-to-device copy they need
+            heads, conv = self._check_heads(heads, deltas.shape[0])
+            converted = converted or conv
         k = self._count % self.depth
         slot = self.slots[k]
         if slot.busy:
@@ -232,12 +241,14 @@ class RoIPathPipeline:
         # how many streams other libraries created first, every marker recorded on it queues behind that stage's kernels:
         # measured 7-14 % of the throughput.)
         cur = torch.cuda.current_stream(dev)
-        slot.wait_in = not cur.query()
+        slot.wait_in = converted or not cur.query()  # a conversion was just enqueued on `cur`: never skip the wait then
         if slot.wait_in:
             self._ev_in[k].record(cur.cuda_stream)
         slot.pending = (fm, heads, timing)
         slot.inputs = (deltas, scores, fm)  # keep alive until the slot comes round again
         slot.busy = True
+        slot.failed = None
+        slot.ticket = self._count
         self._pending.append(k)
         ticket = self._count
         self._count += 1
@@ -245,15 +256,50 @@ class RoIPathPipeline:
             self.flush()
         return ticket
 
+    def _check_heads(self, heads: Any, B: int) -> Tuple[Tuple[torch.Tensor, torch.Tensor], bool]:
+        """Head outputs as contiguous fp32 device tensors of the right shape (ValueError otherwise), and whether that
+        took a conversion.  Any conversion is enqueued on the CURRENT stream: the caller decides which stream that is."""
+        R, L = self._R, int(self.decoder.total_labels)
+        try:
+            pred_deltas, pred_probs = heads
+        except (TypeError, ValueError):
+            raise ValueError("heads must be (pred_deltas, pred_label_probs) or a callable returning them") from None
+        d = _lib.device_tensor(pred_deltas, torch.float32, self.device)
+        p = _lib.device_tensor(pred_probs, torch.float32, self.device)
+        if d.numel() != B * R * L * 4 or tuple(p.shape) != (B, R, L):
+            raise ValueError(f"head outputs {tuple(d.shape)} / {tuple(p.shape)} do not match "
+                             f"({B}, {R}, {L}*4) / ({B}, {R}, {L})")
+        return (d, p), (d is not pred_deltas) or (p is not pred_probs)
+
     def flush(self) -> None:
         """Enqueue the three stages of every submitted batch that is still waiting for its group: ONE proposal launch,
-        ONE crop launch and ONE Decoder launch for all of them (the `*_multi` entry points)."""
+        ONE crop launch and ONE Decoder launch for all of them (the `*_multi` entry points).  If that fails (a head
+        callable raising or returning the wrong shape, an error code from the library) the group's batches are marked
+        failed -- ``result`` raises for them -- and the error propagates."""
         if not self._pending:
             return
-        lib = _lib.lib()
-        dev = self.device
         ks, self._pending = self._pending, []
         slots = [self.slots[k] for k in ks]
+        try:
+            with _lib.on_device(self.device):
+                self._enqueue(ks, slots)
+        except BaseException as exc:
+            try:  # whatever was enqueued for the group on any stage completes before its slots are reused
+                q_prop, q_pool, q_dec = self.s_prop.cuda_stream, self.s_pool.cuda_stream, self.s_dec.cuda_stream
+                self._ev_rois[ks[0]].record(q_prop)
+                self._ev_rois[ks[0]].wait(q_pool)
+                self._ev_heads[ks[0]].record(q_pool)
+                self._ev_heads[ks[0]].wait(q_dec)
+            finally:
+                for s in slots:
+                    s.failed = exc
+                    s.pending = None
+                    s.done.record(self.s_dec.cuda_stream)
+            raise
+
+    def _enqueue(self, ks: List[int], slots: List[_Slot]) -> None:
+        lib = _lib.lib()
+        dev = self.device
         n = len(slots)
         N = self.roi_bbox.anchors.shape[0]
         R, T, L = self._R, int(self.decoder.max_total_size), int(self.decoder.total_labels)
@@ -288,15 +334,15 @@ class RoIPathPipeline:
         for s in slots:
             fm, heads, _ = s.pending
             if callable(heads):
+                # the dense heads run on the pooling stream, and so does any conversion of what they return: the event the
+                # Decoder stage waits for (ev_heads) is recorded on that stream after both
                 with torch.cuda.stream(self.s_pool):
-                    pred_deltas, pred_probs = heads(s.pooled, s.rois)
+                    raw = heads(s.pooled, s.rois)
+                    (pred_deltas, pred_probs), conv = self._check_heads(raw, B)
+                if conv:
+                    s.inputs = s.inputs + (raw,)  # what the conversion reads stays alive until the slot comes round again
             else:
-                pred_deltas, pred_probs = heads
-            pred_deltas = _lib.device_tensor(pred_deltas, torch.float32, dev)
-            pred_probs = _lib.device_tensor(pred_probs, torch.float32, dev)
-            if pred_deltas.numel() != B * R * L * 4 or tuple(pred_probs.shape) != (B, R, L):
-                raise ValueError(f"head outputs {tuple(pred_deltas.shape)} / {tuple(pred_probs.shape)} do not match "
-                                 f"({B}, {R}, {L}*4) / ({B}, {R}, {L})")
+                pred_deltas, pred_probs = heads  # normalised and checked in submit()
             outs.append((pred_deltas, pred_probs))
         ev_heads = self._ev_heads[ks[0]]
         ev_heads.record(q_pool)
@@ -326,6 +372,8 @@ class RoIPathPipeline:
         slot = self.slots[ticket % self.depth]
         if slot.pending is not None:
             self.flush()
+        if slot.failed is not None:
+            raise RuntimeError(f"batch {ticket} was not enqueued: {slot.failed}") from slot.failed
         if wait == "host":
             slot.done.synchronize()
         elif wait == "stream":

@@ -57,8 +57,9 @@ def generate_anchors(hyper_params: HyperParams) -> torch.Tensor:
     coords = torch.tensor(grid_coords, device=device)
     count = base_anchors.shape[0]
     out = torch.empty((feature_map_shape * feature_map_shape * count, 4), dtype=torch.float32, device=device)
-    _lib.check(_lib.lib().frcnn_generate_anchors(_lib.ptr(base_anchors), count, _lib.ptr(coords), feature_map_shape,
-                                                 _lib.ptr(out), _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_generate_anchors(_lib.ptr(base_anchors), count, _lib.ptr(coords), feature_map_shape,
+                                                     _lib.ptr(out), _lib.stream_ptr(device)))
     return out
 
 
@@ -118,10 +119,11 @@ def non_max_suppression(pred_bboxes: torch.Tensor, pred_labels: torch.Tensor, **
     L = _lib.lib()
     nbytes = L.frcnn_combined_nms_workspace_bytes(B, n, q, c, max_per_class, max_total)
     ws = _lib.workspace(nbytes, device)
-    _lib.check(L.frcnn_combined_nms(_lib.ptr(boxes), _lib.ptr(scores), B, n, q, c, max_per_class, max_total,
-                                    iou_threshold, score_threshold, int(clip_boxes), _lib.ptr(out_boxes),
-                                    _lib.ptr(out_scores), _lib.ptr(out_classes), _lib.ptr(out_valid), _lib.ptr(ws),
-                                    ws.numel(), _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(L.frcnn_combined_nms(_lib.ptr(boxes), _lib.ptr(scores), B, n, q, c, max_per_class, max_total,
+                                        iou_threshold, score_threshold, int(clip_boxes), _lib.ptr(out_boxes),
+                                        _lib.ptr(out_scores), _lib.ptr(out_classes), _lib.ptr(out_valid), _lib.ptr(ws),
+                                        ws.numel(), _lib.stream_ptr(device)))
     return CombinedNMSOutput(out_boxes, out_scores, out_classes, out_valid)
 
 
@@ -158,8 +160,9 @@ def get_bboxes_from_deltas(anchors: torch.Tensor, deltas: torch.Tensor,
     first, batched, B, N = _codec_layout(anchors_t, deltas_t)
     out = torch.empty_like(deltas_t)
     var = None if variances is None else _lib.float4(variances)
-    _lib.check(_lib.lib().frcnn_decode_boxes(_lib.ptr(first), batched, _lib.ptr(deltas_t), var, B, N, _lib.ptr(out),
-                                             _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_decode_boxes(_lib.ptr(first), batched, _lib.ptr(deltas_t), var, B, N, _lib.ptr(out),
+                                                 _lib.stream_ptr(device)))
     return out
 
 
@@ -178,8 +181,9 @@ def get_deltas_from_bboxes(bboxes: torch.Tensor, gt_boxes: torch.Tensor,
     first, batched, B, N = _codec_layout(bboxes_t, gt_t)
     out = torch.empty_like(gt_t)
     var = None if variances is None else _lib.float4(variances)
-    _lib.check(_lib.lib().frcnn_encode_boxes(_lib.ptr(first), batched, _lib.ptr(gt_t), var, B, N, _lib.ptr(out),
-                                             _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_encode_boxes(_lib.ptr(first), batched, _lib.ptr(gt_t), var, B, N, _lib.ptr(out),
+                                                 _lib.stream_ptr(device)))
     return out
 
 
@@ -208,8 +212,9 @@ def generate_iou_map(bboxes: torch.Tensor, gt_boxes: torch.Tensor) -> torch.Tens
         raise ValueError(f"bboxes must be (N,4) or (batch,N,4), got {tuple(bboxes_t.shape)}")
     N = bboxes_t.shape[-2]
     out = torch.empty((B, N, M), dtype=torch.float32, device=device)
-    _lib.check(_lib.lib().frcnn_iou_map(_lib.ptr(bboxes_t), batched, _lib.ptr(gt_t), B, N, M, _lib.ptr(out),
-                                        _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_iou_map(_lib.ptr(bboxes_t), batched, _lib.ptr(gt_t), B, N, M, _lib.ptr(out),
+                                            _lib.stream_ptr(device)))
     return out
 
 
@@ -226,7 +231,8 @@ def top_k(values: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     k = int(k)
     out_v = torch.empty((B, k), dtype=torch.float32, device=v.device)
     out_i = torch.empty((B, k), dtype=torch.int32, device=v.device)
-    _lib.check(_lib.lib().frcnn_top_k(_lib.ptr(v), B, N, k, _lib.ptr(out_v), _lib.ptr(out_i), _lib.stream_ptr(v.device)))
+    with _lib.on_device(v.device):
+        _lib.check(_lib.lib().frcnn_top_k(_lib.ptr(v), B, N, k, _lib.ptr(out_v), _lib.ptr(out_i), _lib.stream_ptr(v.device)))
     return out_v, out_i
 
 
@@ -259,24 +265,8 @@ def crop_and_resize(image: torch.Tensor, boxes: torch.Tensor, box_indices: torch
         raise ValueError("box_index has values outside [0, batch_size)")
     ch, cw = int(crop_size[0]), int(crop_size[1])
     out = torch.empty((n, ch, cw, C), dtype=torch.float32, device=device)
-    _lib.check(_lib.lib().frcnn_crop_and_resize(_lib.ptr(img), B, H, W, C, _lib.ptr(bx), _lib.ptr(ind), n, 0, ch, cw,
-                                                float(extrapolation_value), _lib.ptr(out), _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_crop_and_resize(_lib.ptr(img), B, H, W, C, _lib.ptr(bx), _lib.ptr(ind), n, 0, ch, cw,
+                                                    float(extrapolation_value), _lib.ptr(out), _lib.stream_ptr(device)))
     return out
 
-
-def normalize_bboxes(bboxes: torch.Tensor, height: Any, width: Any) -> torch.Tensor:
-    """Pixel -> normalised boxes (reference ``utils/bbox_utils.py:163-178``; drawing helper, torch ops)."""
-    y1 = bboxes[..., 0] / height
-    x1 = bboxes[..., 1] / width
-    y2 = bboxes[..., 2] / height
-    x2 = bboxes[..., 3] / width
-    return torch.stack([y1, x1, y2, x2], dim=-1)
-
-
-def denormalize_bboxes(bboxes: torch.Tensor, height: Any, width: Any) -> torch.Tensor:
-    """Normalised -> pixel boxes (reference ``utils/bbox_utils.py:181-197``; drawing helper, torch ops)."""
-    y1 = bboxes[..., 0] * height
-    x1 = bboxes[..., 1] * width
-    y2 = bboxes[..., 2] * height
-    x2 = bboxes[..., 3] * width
-    return torch.round(torch.stack([y1, x1, y2, x2], dim=-1))

@@ -46,8 +46,9 @@ def match_predictions(pred_bboxes: torch.Tensor, gt_boxes: torch.Tensor) -> Tupl
     M = gt.shape[1]
     merged = torch.empty((B, R), dtype=torch.float32, device=device)
     arg = torch.empty((B, R), dtype=torch.int32, device=device)
-    _lib.check(_lib.lib().frcnn_iou_map_reduce(_lib.ptr(pred), 1, _lib.ptr(gt), B, R, M, _lib.ptr(merged), _lib.ptr(arg),
-                                               None, None, 0, _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_iou_map_reduce(_lib.ptr(pred), 1, _lib.ptr(gt), B, R, M, _lib.ptr(merged), _lib.ptr(arg),
+                                                   None, None, 0, _lib.stream_ptr(device)))
     _, sorted_ids = bbox_utils.top_k(merged, R)
     return merged, arg, sorted_ids
 

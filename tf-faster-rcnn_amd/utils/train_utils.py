@@ -94,8 +94,9 @@ def randomly_select_xyz_mask(mask: torch.Tensor, select_xyz: Any,
             raise ValueError("random_mask must have the shape of mask")
     m8 = m.view(torch.uint8)
     out = torch.empty((B, N), dtype=torch.uint8, device=device)
-    _lib.check(_lib.lib().frcnn_select_mask(_lib.ptr(m8), _lib.ptr(rnd), _lib.ptr(sel), sel.numel(), B, N,
-                                            _lib.ptr(out), _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(_lib.lib().frcnn_select_mask(_lib.ptr(m8), _lib.ptr(rnd), _lib.ptr(sel), sel.numel(), B, N,
+                                                _lib.ptr(out), _lib.stream_ptr(device)))
     return out.view(torch.bool)
 
 
@@ -155,9 +156,10 @@ def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, 
     L = _lib.lib()
     nbytes = L.frcnn_rpn_targets_workspace_bytes(B, N, M)
     ws = _lib.workspace(nbytes, device)
-    _lib.check(L.frcnn_rpn_targets(_lib.ptr(anchors_t), _lib.ptr(gt_t), _lib.ptr(lab_t), _lib.ptr(rp), _lib.ptr(rn),
-                                   int(seed) & 0xFFFFFFFFFFFFFFFF, B, N, M, total_pos, total_neg, variances,
-                                   _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
+    with _lib.on_device(device):
+        _lib.check(L.frcnn_rpn_targets(_lib.ptr(anchors_t), _lib.ptr(gt_t), _lib.ptr(lab_t), _lib.ptr(rp), _lib.ptr(rn),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, B, N, M, total_pos, total_neg, variances,
+                                       _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
     return deltas, labels.reshape(B, feature_map_shape, feature_map_shape, anchor_count)
 
 
