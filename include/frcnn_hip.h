@@ -133,6 +133,16 @@ int frcnn_crop_and_resize(const float *image, int B, int H, int W, int C, const 
                           int crop_w, float extrapolation_value, float *out,
                           frcnn_stream_t stream);
 
+/* models/faster_rcnn.py:264-293 RoIPooling.call as one entry point: RoI r of image b samples image b (:280-282),
+ * bilinear crop_and_resize to (crop_h, crop_w) with extrapolation value 0 (:283-288).  feature_map (B,H,W,C); rois (B,R,4);
+ * out (B,R,crop_h,crop_w,C).  Same results as frcnn_crop_and_resize(box_ind = NULL, boxes_per_image = R).  The optional
+ * workspace (frcnn_roi_pooling_workspace_bytes; NULL = none) lets feature maps larger than an XCD's L2 be swept in spatial
+ * order: every image's RoIs are visited top to bottom, each output still written to its own slot. */
+size_t frcnn_roi_pooling_workspace_bytes(int B, int R);
+int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
+                      int crop_h, int crop_w, float *out, void *workspace, size_t workspace_bytes,
+                      frcnn_stream_t stream);
+
 /* The same operation (models/faster_rcnn.py:283-288, RoIPooling layout: box_ind == NULL) for `groups` (1..4)
  * independent batches of one shape in ONE launch: images / boxes / outs are HOST arrays of `groups` device pointers
  * ((B,H,W,C), (n,4), (n,ch,cw,C) each).  The reference calls the layer once per batch; a serving loop that has

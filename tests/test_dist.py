@@ -60,3 +60,46 @@ def test_sharded_path_matches_single_process(tmp_path, batch):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_worker, args=(2, _free_port(), batch, out), nprocs=2, join=True)
     assert np.load(out)[0]
+
+
+def _gather_worker(rank: int, world: int, port: int, batch: int, out_path: str) -> None:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = None
+    try:
+        from tf_faster_rcnn_amd import sharding
+
+        sections = [("roi_bboxes", (5, 4), torch.float32), ("valid", (4,), torch.int32)]
+        sh = sharding.SharedHostGather(sections, batch, slots=2, device=None)  # no GPU here: rows are copied by the host
+        lo, hi = sharding.shard_bounds(batch, rank, world)
+        assert (sh.lo, sh.hi) == (lo, hi)
+        full_r = torch.arange(batch * 20, dtype=torch.float32).view(batch, 5, 4)
+        full_v = torch.arange(batch * 4, dtype=torch.int32).view(batch, 4)
+        for step in range(3):  # three steps through a ring of two slots
+            sh.write_step(step, {"roi_bboxes": (full_r[lo:hi] + step).contiguous(), "valid": (full_v[lo:hi] * (step + 1)).contiguous()})
+        sh.flush()
+        dist.barrier()  # every rank's rows are in place
+        ok = True
+        for step in (1, 2):  # the two steps still in the ring, seen whole by EVERY rank
+            ok &= torch.equal(sh.view(step, "roi_bboxes"), full_r + step)
+            ok &= torch.equal(sh.view(step, "valid"), full_v * (step + 1))
+        dist.barrier()  # (the failing write below may touch this rank's rows before it raises)
+        with pytest.raises(ValueError):
+            sh.write_step(0, {"roi_bboxes": full_r[lo:hi].contiguous(), "valid": full_v[lo:hi].float()})
+        dist.barrier()
+        np.save(f"{out_path}.{rank}.npy", np.array([ok]))
+    finally:
+        if sh is not None:
+            sh.close()
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [6, 5, 2])
+def test_shared_host_gather_layout(tmp_path, batch):
+    """sharding.SharedHostGather: every rank writes its shard's rows into ONE shared host buffer in shard order; after a
+    barrier every rank sees the whole batch.  (On a GPU the rows are written by frcnn_gather_copy: tests/test_gpu_dist.py.)"""
+    out = str(tmp_path / "ok")
+    mp.spawn(_gather_worker, args=(2, _free_port(), batch, out), nprocs=2, join=True)
+    assert np.load(out + ".0.npy")[0] and np.load(out + ".1.npy")[0]

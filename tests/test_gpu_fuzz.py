@@ -91,6 +91,59 @@ def test_fuzz_roi_pooling(pkg, knobs):
         assert_bits(got, want, f"RoIPooling fuzz case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw})")
 
 
+def test_fuzz_roi_pooling_warmup_workgroups(pkg, knobs):
+    """The box kernel with warm-up workgroups in its slot sequence (FRCNN_CROP_PREFETCH = n per image; default 48 for large
+    feature maps): every box is still written exactly once, whatever the number of images per XCD range, boxes per image
+    (fewer or more than the 128-box lead) and warm-up workgroups -- also through the grouped launch."""
+    rng = np.random.default_rng(19)
+    lib = pkg._lib.lib()
+    for case in range(60):
+        B = int(rng.integers(1, 20))
+        H, W = int(rng.integers(2, 12)), int(rng.integers(2, 12))
+        C = int(rng.choice([4, 8, 64]))
+        R = int(rng.choice([1, 2, 7, 8, 9, 31, 127, 128, 129, 300]))
+        knobs.setenv("FRCNN_CROP_PREFETCH", int(rng.choice([1, 2, 5, 48, 200])))
+        fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+        rois = rng.uniform(-0.1, 1.1, (B, R, 4)).astype(np.float32)
+        hp = synth.hyper_params(pooling_size=(3, 2))
+        want = oracle.roi_pooling(fm, rois, (3, 2))
+        got = pkg.faster_rcnn.RoIPooling(hp)([dev(fm), dev(rois)])
+        assert_bits(got, want, f"RoIPooling warm-up case {case}: B={B} H={H} W={W} C={C} R={R}")
+        if case % 3 == 0:  # grouped launch: the same triple g times, outputs poisoned first
+            g = 2 + case % 3
+            fms, rs = [dev(fm) for _ in range(g)], [dev(rois) for _ in range(g)]
+            outs = [torch.full((B, R, 3, 2, C), float("nan"), device="cuda") for _ in range(g)]
+            tab = pkg._lib.ptr_table
+            pkg._lib.check(lib.frcnn_crop_and_resize_multi(tab(fms), tab(rs), tab(outs), g, B, H, W, C, B * R, R, 3, 2, 0.0,
+                                                           torch.cuda.current_stream().cuda_stream))
+            for o in outs:
+                assert_bits(o, want, f"grouped RoIPooling warm-up case {case}: g={g} B={B} R={R}")
+
+
+def test_fuzz_roi_pooling_sorted_channel_split(pkg, knobs):
+    """frcnn_roi_pooling's schedule for feature maps beyond an XCD's L2, forced on small shapes: channels cut over 2 / 4 / 8
+    XCDs, the RoIs of every image visited in spatial order (or not); outputs land in their own slots, bit-exact."""
+    rng = np.random.default_rng(23)
+    for case in range(72):
+        B = int(rng.integers(1, 7))
+        H, W = int(rng.integers(1, 14)), int(rng.integers(1, 14))
+        C = int(rng.choice([4, 8, 12, 36, 64, 576]))
+        R = int(rng.choice([1, 2, 3, 17, 64, 300, 1025]))
+        ph, pw = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        knobs.setenv("FRCNN_CROP_SPLIT", [2, 4, 8][case % 3])
+        knobs.setenv("FRCNN_CROP_SORT", (case // 3) % 2)
+        fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+        rois = rng.uniform(-0.2, 1.2, (B, R, 4)).astype(np.float32)
+        if case % 5 == 0:
+            rois[0, : R // 2] = rois[0, 0]  # equal keys: ties by index
+        if case % 7 == 0:
+            rois[-1, -1, 0] = np.nan  # a NaN centre must not break the permutation
+        hp = synth.hyper_params(pooling_size=(ph, pw))
+        got = pkg.faster_rcnn.RoIPooling(hp)([dev(fm), dev(rois)])
+        want = oracle.roi_pooling(fm, rois, (ph, pw))
+        assert_bits(got, want, f"RoIPooling split case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw})")
+
+
 def test_fuzz_decoder(pkg, knobs):
     rng = np.random.default_rng(11)
     for case in range(240):

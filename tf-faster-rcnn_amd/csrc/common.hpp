@@ -40,6 +40,9 @@ enum Knob {
   kKnobProposalThreads,  // FRCNN_PROPOSAL_THREADS      256|1024
   kKnobIouTile,          // FRCNN_IOU_TILE              elements per lane of the flat IoU-map kernel
   kKnobIouMapFlat,       // FRCNN_IOU_MAP_FLAT          1
+  kKnobCropPrefetch,     // FRCNN_CROP_PREFETCH         workgroups per XCD of the feature-map warm-up pass (0 = none)
+  kKnobCropSplit,        // FRCNN_CROP_SPLIT            channel slices of frcnn_roi_pooling's large-image schedule (0 | 2 | 4 | 8)
+  kKnobCropSort,         // FRCNN_CROP_SORT             0 = keep the RoIs in their given order there
   kKnobCount
 };
 bool knob_set(Knob k);

@@ -139,21 +139,94 @@ __device__ __forceinline__ vec_t bilerp(const char *__restrict__ base, const Pix
   return v;
 }
 
-// Channel-slice kernel for feature maps that do not fit an XCD's L2 (e.g. 63x63x576 = 9.1 MB per image): the 8 XCDs
-// each own one eighth of the channels (blockIdx % 8 = slice) and all of them walk the boxes in order, so an XCD's L2 only
-// has to hold 1/8 of the current image.  One workgroup = (box, slice): ch*cw segments of SW float4, strided by C floats.
+// Feature maps that are cold (in HBM, not in L2 / Infinity Cache) cost the box kernel a third of its speed: its taps are
+// scattered 16-B-per-lane loads whose misses queue behind the kernel's own write stream (measured at config 2 with input
+// sets rotating through 650 MB: 134 us per batch against 100 us warm).  So the launch carries WARM-UP WORKGROUPS: per XCD
+// and per image of the XCD's box range, pf_blocks workgroups that read the image once with full-line coalesced loads and
+// discard it.  They sit in the XCD's slot sequence pf_lead boxes ahead of the image's first box -- workgroups are
+// dispatched in blockIdx order -- so an image streams into the L2 that is going to sample it while the boxes of the
+// previous image are still being written, and no second launch (with its drain and launch gap) is needed.
+//
+// Slot sequence of one XCD over its boxes [start, start + count): for every image j of the range, in order,
+//   [boxes up to p_j)  [pf_blocks warm-up workgroups of image j]      p_0 = start, p_j = max(p_{j-1}, first box of j - pf_lead)
+// then the remaining boxes.  Returns the box of this slot, or -1 with (*pf_img, *pf_piece) set for a warm-up slot, or -2
+// for a slot past the end.
+__device__ __forceinline__ int crop_slot_role(int slot, int start, int count, int npg, int bpi, int pf_blocks, int pf_lead,
+                                              int *pf_box) {
+  int v = slot;
+  int cb = start;  // next box not yet placed in the sequence
+  const int end = start + count;
+  int first = start;  // first box (of this XCD's range) of the image under consideration
+  while (first < end) {
+    int p = first - pf_lead;
+    if (p < cb) p = cb;
+    const int nb = p - cb;
+    if (v < nb) return cb + v;
+    v -= nb;
+    cb = p;
+    if (v < pf_blocks) {
+      *pf_box = first;
+      return -1 - v;  // warm-up piece v of the image that box `first` samples
+    }
+    v -= pf_blocks;
+    const int lb = first % npg;  // box index inside its triple
+    first += bpi - (lb % bpi);   // first box of the next image
+  }
+  return (cb + v < end) ? cb + v : -1000000;
+}
+
+// Channel-slice kernel for feature maps that do not fit an XCD's L2 (e.g. 63x63x576 = 9.1 MB per image).  The channels
+// are cut into S slices (S = 2, 4 or 8); the 8 XCDs form 8/S lane groups of S XCDs; a lane group walks a contiguous range
+// of boxes and each of its XCDs (blockIdx % 8 = lane group * S + slice) samples only its slice, so an XCD's L2 has to
+// hold 1/S of an image.  One workgroup = (box, slice): ch*cw segments of SW float4, strided by C floats.
+// `order` (optional): the boxes of every image in spatial order (roi_order_kernel); the lane group then sweeps an image
+// top to bottom and the boxes in flight at any moment share a band of source rows instead of being spread over the whole
+// image (RoIBBox emits them in score order, i.e. spatially at random).  Every box is still written to its own slot.
 __global__ __launch_bounds__(256) void crop_resize_slice_kernel(
     const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
-    const int *__restrict__ box_ind, int n, int boxes_per_image, int ch, int cw, float extrap,
-    float *__restrict__ out, int SW) {
+    const int *__restrict__ box_ind, const int *__restrict__ order, int n, int boxes_per_image, int ch, int cw, float extrap,
+    float *__restrict__ out, int S, int SW, int pf_blocks, int pf_lead) {
   __shared__ PixParam pp[256];
   const int tid = threadIdx.x;
-  const int slice = blockIdx.x & 7;
-  const int box = blockIdx.x >> 3;
+  const int grp = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int nlg = 8 / S;
+  const int slice = grp % S, lg = grp / S;
+  const int q = n / nlg, r = n - q * nlg;
+  const int start = (lg < r) ? lg * (q + 1) : r * (q + 1) + (lg - r) * q;
+  const int count = q + (lg < r ? 1 : 0);
   const int CV = C >> 2;
   const int c0 = slice * SW;
   const int sw = (CV - c0 < SW) ? (CV - c0) : SW;  // float4 channels of this slice (may be <= 0 for the last ones)
   if (sw <= 0) return;
+  int unit;
+  if (pf_blocks > 0) {
+    // warm-up workgroups in the slot sequence (see crop_slot_role): this XCD's slice of an image, streamed into its L2
+    // pf_lead boxes before the image's first box (RoIPooling layout only: box_ind == NULL, order == NULL)
+    int pf_box = 0;
+    const int role = crop_slot_role(slot, start, count, n, boxes_per_image, pf_blocks, pf_lead, &pf_box);
+    if (role <= -1000000) return;
+    if (role < 0) {
+      const int piece = -1 - role;
+      const int img_i = pf_box / boxes_per_image;
+      if (img_i >= B) return;
+      const char *src = reinterpret_cast<const char *>(image + (long long)img_i * H * W * C) + (size_t)c0 * 16;
+      const int total = H * W * sw;  // float4 of the slice
+      f32x4 acc = (f32x4)(0.0f);
+      for (int e = piece * 256 + tid; e < total; e += pf_blocks * 256) {
+        const int px = e / sw, c = e - px * sw;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)px * ((size_t)C * 4) + (size_t)c * 16);
+        acc.x += v.x;  // (any use keeps the load; nothing is stored)
+      }
+      asm volatile("" ::"v"(acc));
+      return;
+    }
+    unit = role;
+  } else {
+    if (slot >= count) return;
+    unit = start + slot;
+  }
+  const int box = order ? order[unit] : unit;
   const int bimg = box_ind ? box_ind[box] : (box / boxes_per_image);
   const bool img_ok = (bimg >= 0) && (bimg < B);
   const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + (long long)box * 4);
@@ -195,6 +268,29 @@ __global__ __launch_bounds__(256) void crop_resize_slice_kernel(
   }
 }
 
+// order[b*R + rank] = b*R + i, rank = position of RoI i of image b when the image's RoIs are sorted by vertical centre
+// (ties by index; total order on the float bits, so NaN boxes land somewhere instead of breaking the permutation).
+// One workgroup per image, R <= 1024 keys in LDS, rank by counting: R*R/256 LDS reads per lane (~3 us at R = 300).
+__global__ __launch_bounds__(256) void roi_order_kernel(const float *__restrict__ rois, int R, int *__restrict__ order) {
+  __shared__ uint32_t key[1024];
+  const int b = blockIdx.x;
+  const float *rb = rois + (long long)b * R * 4;
+  for (int i = threadIdx.x; i < R; i += 256) {
+    const f32x4 bx = *reinterpret_cast<const f32x4 *>(rb + (long long)i * 4);
+    key[i] = f_order_key(bx.x + bx.z);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < R; i += 256) {
+    const uint32_t k = key[i];
+    int rank = 0;
+    for (int j = 0; j < R; ++j) {
+      const uint32_t kj = key[j];
+      rank += (kj < k) || (kj == k && j < i);
+    }
+    order[(long long)b * R + rank] = b * R + i;
+  }
+}
+
 #ifndef FRCNN_CROP_WAVES_PER_EU
 #define FRCNN_CROP_WAVES_PER_EU 4
 #endif
@@ -209,9 +305,12 @@ struct CropGroups {
   const float *boxes[kCropGroups];
   float *out[kCropGroups];
   int n_per_group;  // boxes per triple; 0 = a single triple (no group arithmetic)
+  // warm-up workgroups (PF kernels only; RoIPooling layout: box_ind == NULL, every image has boxes_per_image boxes)
+  int pf_blocks;    // workgroups that stream one image into the XCD's L2
+  int pf_lead;      // ... dispatched this many boxes before the image's first box
 };
 
-template <int VEC, bool ROWS, int WPE>
+template <int VEC, bool ROWS, int WPE, bool PF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void crop_resize_kernel(
     CropGroups gr, int B, int H, int W, int C,
@@ -226,7 +325,33 @@ void crop_resize_kernel(
   const int slot = blockIdx.x >> 3;
   const int q = units >> 3, r = units & 7;
   const int start = (grp < r) ? grp * (q + 1) : r * (q + 1) + (grp - r) * q;
-  const int unit = start + slot;
+  int unit = start + slot;
+  if (PF) {
+    const int npg = gr.n_per_group > 0 ? gr.n_per_group : units;
+    int pf_box = 0;
+    const int role = crop_slot_role(slot, start, q + (grp < r ? 1 : 0), npg, boxes_per_image, gr.pf_blocks, gr.pf_lead, &pf_box);
+    if (role <= -1000000) return;
+    if (role < 0) {
+      const int piece = -1 - role;
+      const int g = pf_box / npg;
+      const int img_i = (pf_box - g * npg) / boxes_per_image;
+      const float *image = gr.image[0];
+#pragma unroll
+      for (int i = 1; i < kCropGroups; ++i)
+        if (g == i) image = gr.image[i];
+      if (img_i >= B) return;
+      const long long image_bytes = (long long)H * W * C * 4;
+      const char *src = reinterpret_cast<const char *>(image) + (long long)img_i * image_bytes;
+      f32x4 acc = (f32x4)(0.0f);
+      for (long long o = ((long long)piece * 256 + tid) * 16; o + 16 <= image_bytes; o += (long long)gr.pf_blocks * 256 * 16) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + o);
+        acc.x += v.x;  // (any use keeps the load; nothing is stored)
+      }
+      asm volatile("" ::"v"(acc));
+      return;
+    }
+    unit = role;
+  }
   int box = ROWS ? unit / ch : unit;
   const int pbeg = ROWS ? (unit - box * ch) * cw : 0;  // first output pixel of this workgroup
   // which triple (workgroup-uniform; selects instead of indexing the kernel-argument arrays dynamically)
@@ -306,6 +431,29 @@ void crop_resize_kernel(
   }
 }
 
+// Whether a launch over `units` boxes carries warm-up workgroups, and its grid then (0 = no).  FRCNN_CROP_PREFETCH = n
+// forces n warm-up workgroups per image (0 = none); by default 192 of them (measured 24 / 48 / 96 / 192 / 288 / 576 ->
+// 103 / 116 / 121 / 123 / 123 / 119 k images/s in the stage pipeline, cold inputs) when the batch's feature maps exceed one XCD's
+// L2 (a single small image is sampled by every XCD at once and needs none).
+static unsigned crop_warmup_grid(CropGroups &gr, int units, int boxes_per_image, int B, long long image_bytes) {
+  int pf = knob(kKnobCropPrefetch, -1);
+  if (pf < 0) pf = (image_bytes * B > 4ll * 1024 * 1024 && image_bytes >= 256 * 1024) ? 192 : 0;
+  int lead = 256;  // twice the boxes resident per XCD (32 CUs x 4 workgroups): measured 64 / 128 / 256 -> 120.7 / 121.4 / 124.3 k images/s
+  if (pf >= 10000) {  // diagnostic: lead * 10000 + workgroups
+    lead = pf / 10000;
+    pf %= 10000;
+  }
+  if (pf <= 0 || units < 8 || boxes_per_image <= 0) return 0;
+  if (pf > 1024) pf = 1024;
+  gr.pf_blocks = pf;
+  gr.pf_lead = lead;
+  const int qmax = (units + 7) / 8;
+  const long long images_max = (qmax + boxes_per_image - 2) / boxes_per_image + 1;  // images an XCD's range can touch
+  const long long slots = qmax + images_max * pf;
+  if (slots * 8 >= (1ll << 31)) return 0;
+  return (unsigned)(slots * 8);
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -337,7 +485,7 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   if (use_slice) {
     const int CV = C / 4, SW = (CV + 7) / 8;
     hipLaunchKernelGGL(crop_resize_slice_kernel, dim3((unsigned)n * 8u), block, 0, (hipStream_t)stream, image, B, H, W, C,
-                       boxes, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out, SW);
+                       boxes, box_ind, (const int *)nullptr, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out, 8, SW, 0, 0);
     return check_launch("crop_and_resize");
   }
   // FRCNN_CROP_ROWS=0|1 forces the (box) / (box, output row) decomposition (diagnostic).
@@ -352,13 +500,73 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
     hipLaunchKernelGGL((crop_resize_kernel<4, true, 6>), dim3((unsigned)(n * crop_h)), block, 0, (hipStream_t)stream, gr,
                        B, H, W, C, box_ind, n * crop_h, boxes_per_image, crop_h, crop_w, extrapolation_value);
   } else if (vec4) {
-    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
-                       B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
+    unsigned pf_grid = 0;
+    if (!box_ind && (pf_grid = crop_warmup_grid(gr, n, boxes_per_image, B, (long long)H * W * C * 4)) != 0)
+      hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU, true>), dim3(pf_grid), block, 0, (hipStream_t)stream,
+                         gr, B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
+    else
+      hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
+                         B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
   } else {
     hipLaunchKernelGGL((crop_resize_kernel<1, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
                        B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
   }
   return check_launch("crop_and_resize");
+}
+
+extern "C" size_t frcnn_roi_pooling_workspace_bytes(int B, int R) {
+  if (B <= 0 || R <= 0) return 256;
+  return round_up((size_t)B * R * sizeof(int), 256) + 256;
+}
+
+extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
+                                 int crop_h, int crop_w, float *out, void *workspace, size_t workspace_bytes,
+                                 frcnn_stream_t stream) {
+  FRCNN_REQUIRE(feature_map && rois && out, "roi_pooling: null pointer");
+  FRCNN_REQUIRE(B >= 0 && R >= 0, "roi_pooling: negative shape");
+  if (B == 0 || R == 0) return FRCNN_OK;
+  FRCNN_REQUIRE((long long)B * R < (1ll << 28), "roi_pooling: too many RoIs");
+  const int n = B * R;
+  const long long image_bytes = (long long)H * W * C * 4;
+  // Feature maps beyond an XCD's 4 MiB L2 (config 5: 9.1 MB) take the channel-slice kernel with the channels cut over all
+  // 8 XCDs.  Measured at config 5 (16 images, cold inputs, us per launch; profiles/r02_*cfg5*): S = 8 217-230, S = 4 222,
+  // S = 2 214, box kernel 240; sweeping every image's RoIs top to bottom (FRCNN_CROP_SORT=1, roi_order_kernel) is SLOWER
+  // (S = 8 279, S = 4 253-266, S = 2 246) although its HBM traffic is ideal (FETCH 160 MB for 146 MB of feature maps,
+  // WRITE 537 MB); warm-up workgroups (FRCNN_CROP_PREFETCH) do not help the slice kernel either (S = 8 273, S = 4 221).
+  // FRCNN_CROP_SPLIT = S forces S (0 = never this schedule).
+  int S = knob(kKnobCropSplit, -1);
+  if (S < 0) S = image_bytes <= 4ll * 1024 * 1024 ? 0 : 8;
+  const bool shape_ok = H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
+                        aligned_to(out, 16) && aligned_to(rois, 16) && (long long)crop_h * crop_w * C * 4 < (1ll << 32) &&
+                        image_bytes < (1ll << 32) && (long long)crop_h * crop_w < (1ll << 24);
+  if ((S == 2 || S == 4 || S == 8) && shape_ok) {
+    const int *order = nullptr;
+    const bool sort = knob(kKnobCropSort, 0) != 0 && R <= 1024 && workspace && aligned_to(workspace, 256) &&
+                      workspace_bytes >= frcnn_roi_pooling_workspace_bytes(B, R);
+    if (sort) {
+      int *ord = reinterpret_cast<int *>(workspace);
+      hipLaunchKernelGGL(roi_order_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, rois, R, ord);
+      int rc = check_launch("roi_pooling (RoI order)");
+      if (rc) return rc;
+      order = ord;
+    }
+    const int CV = C / 4, SW = (CV + S - 1) / S, nlg = 8 / S;
+    long long slots = (n + nlg - 1) / nlg;
+    // warm-up workgroups (unsorted sweep only: a sorted sweep has no "first box of the next image" in slot order that
+    // the image-by-image warm-up could lead): FRCNN_CROP_PREFETCH as for the box kernel; off by default (no gain measured)
+    int pf = order ? 0 : knob(kKnobCropPrefetch, 0), lead = 128;
+    if (pf >= 10000) {
+      lead = pf / 10000;
+      pf %= 10000;
+    }
+    if (pf > 1024) pf = 1024;
+    if (pf > 0) slots += ((slots + R - 2) / R + 1) * pf;
+    FRCNN_REQUIRE(slots * 8 < (1ll << 31), "roi_pooling: too many workgroups");
+    hipLaunchKernelGGL(crop_resize_slice_kernel, dim3((unsigned)slots * 8u), dim3(256), 0, (hipStream_t)stream, feature_map, B, H,
+                       W, C, rois, (const int *)nullptr, order, n, R, crop_h, crop_w, 0.0f, out, S, SW, pf, lead);
+    return check_launch("roi_pooling");
+  }
+  return frcnn_crop_and_resize(feature_map, B, H, W, C, rois, nullptr, n, R, crop_h, crop_w, 0.0f, out, stream);
 }
 
 extern "C" int frcnn_crop_and_resize_multi(const float *const *images, const float *const *boxes, float *const *outs,
@@ -395,8 +603,13 @@ extern "C" int frcnn_crop_and_resize_multi(const float *const *images, const flo
     gr.out[g] = outs[s];
   }
   gr.n_per_group = n;
-  hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), dim3((unsigned)(n * groups)), dim3(256), 0,
-                     (hipStream_t)stream, gr, B, H, W, C, (const int *)nullptr, n * groups, boxes_per_image, crop_h, crop_w,
-                     extrapolation_value);
+  if (const unsigned pf_grid = crop_warmup_grid(gr, n * groups, boxes_per_image, B, (long long)H * W * C * 4))
+    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU, true>), dim3(pf_grid), dim3(256), 0,
+                       (hipStream_t)stream, gr, B, H, W, C, (const int *)nullptr, n * groups, boxes_per_image, crop_h, crop_w,
+                       extrapolation_value);
+  else
+    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), dim3((unsigned)(n * groups)), dim3(256), 0,
+                       (hipStream_t)stream, gr, B, H, W, C, (const int *)nullptr, n * groups, boxes_per_image, crop_h, crop_w,
+                       extrapolation_value);
   return check_launch("crop_and_resize_multi");
 }

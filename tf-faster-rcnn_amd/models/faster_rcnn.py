@@ -266,7 +266,9 @@ class RoIPooling(Layer):
         R = rois.shape[1]
         out = torch.empty((B, R, ph, pw, C), dtype=torch.float32, device=device)
         if B * R:
+            lib = _lib.lib()
+            ws = _lib.workspace(lib.frcnn_roi_pooling_workspace_bytes(B, R), device)
             with _lib.on_device(device):
-                _lib.check(_lib.lib().frcnn_crop_and_resize(_lib.ptr(fm), B, H, W, C, _lib.ptr(rois), None, B * R, R, ph, pw,
-                                                            0.0, _lib.ptr(out), _lib.stream_ptr(device)))
+                _lib.check(lib.frcnn_roi_pooling(_lib.ptr(fm), B, H, W, C, _lib.ptr(rois), R, ph, pw, _lib.ptr(out), _lib.ptr(ws),
+                                                 ws.numel(), _lib.stream_ptr(device)))
         return out

@@ -59,3 +59,155 @@ def gather_to_host(local: torch.Tensor, batch: int, group=None, dst: int = 0) ->
     if rank != dst:
         return None
     return torch.cat([p for p in parts if p is not None and p.shape[0] > 0] or [host[:0]], dim=0)
+
+
+class SharedHostGather:
+    """The final host gather of a batch that is sharded over the GPUs of one node, with no collective: ONE host buffer in
+    POSIX shared memory holds the outputs of the whole (global) batch in shard order, every rank maps it, and every rank
+    puts its own images' rows in their place.  On a GPU the rows travel in two hops: a copy kernel on the rank's stream
+    (``frcnn_gather_copy``) writes them into a pinned staging ring, and the host moves a staged step into the shared
+    buffer once the step's event has completed -- ``slots - 1`` steps later in a running loop, so the host never waits for
+    the GPU.  (Writing from the GPU straight into the shared mapping needs ``hipHostRegister``, which this platform
+    refuses for ordinary users, shared or anonymous mappings alike: measured, rc = invalid argument.)  When every rank has
+    ``flush``-ed (and the caller's barrier has passed) any rank -- normally rank 0 -- reads the concatenated result from
+    ``view``.
+
+    The reference is single-device and returns host arrays from ``predict`` (faster_rcnn_predictor.py:56); this is what
+    that becomes when the batch is cut over several processes.
+
+    Args:
+        sections: ``(name, per_image_shape, dtype)`` of every gathered output, e.g. ``("roi_bboxes", (300, 4), torch.float32)``.
+            A row (one image of one section) must be a multiple of 16 bytes.
+        batch: images of the global batch.
+        slots: ring depth: step ``s`` lives in slot ``s % slots`` of the staging ring and of the shared buffer, so a reader
+            has ``slots - 1`` steps to look at a published step.
+        rank, world_size: this process's position; default from the initialised process group, else 0 of 1.
+        device: the GPU that produces the rows (None = no GPU: rows are host tensors; used by the CPU tests of the layout).
+        name: shared-memory name; rank 0 creates it and broadcasts it through the process group when omitted.
+    """
+
+    def __init__(self, sections: Sequence[Tuple[str, Tuple[int, ...], torch.dtype]], batch: int, slots: int = 2,
+                 rank: Optional[int] = None, world_size: Optional[int] = None, device: Optional[torch.device] = None,
+                 name: Optional[str] = None, group=None) -> None:
+        from multiprocessing import shared_memory
+
+        import numpy as np
+        import torch.distributed as dist
+
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.rank = (dist.get_rank(group) if have_pg else 0) if rank is None else rank
+        self.world = (dist.get_world_size(group) if have_pg else 1) if world_size is None else world_size
+        self.batch, self.slots, self.device = int(batch), int(slots), device
+        if self.slots < 1:
+            raise ValueError("slots must be >= 1")
+        self.lo, self.hi = shard_bounds(self.batch, self.rank, self.world)
+        n_loc = self.hi - self.lo
+        self._layout = {}
+        off = loc = 0
+        for sec_name, shape, dtype in sections:
+            row = int(np.prod(shape, dtype=np.int64)) * torch.empty((), dtype=dtype).element_size()
+            if row % 16:
+                raise ValueError(f"section {sec_name}: one image is {row} bytes, must be a multiple of 16")
+            self._layout[sec_name] = (off, tuple(shape), dtype, row, loc)  # offsets in the shared slot / in the staging slot
+            off += (row * self.batch + 255) // 256 * 256
+            loc += (row * n_loc + 255) // 256 * 256
+        self.slot_bytes, self._stage_bytes = off, max(loc, 256)
+        total = max(off * self.slots, 256)
+        if self.rank == 0:
+            self._shm = shared_memory.SharedMemory(create=True, size=total, name=name)
+            names = [self._shm.name]
+        else:
+            names = [name]
+        if name is None and self.world > 1:
+            if not have_pg:
+                raise ValueError("world_size > 1 needs an initialised process group or an explicit name")
+            dist.broadcast_object_list(names, src=0, group=group)  # also orders creation before the other ranks' open
+        elif self.world > 1 and have_pg:
+            dist.barrier(group)
+        if self.rank != 0:
+            self._shm = shared_memory.SharedMemory(name=names[0])
+            try:  # the creator unlinks; keep this process's resource tracker from doing it a second time at exit
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self._shm._name, "shared_memory")  # type: ignore[attr-defined]
+            except Exception:
+                pass
+        self._np = np.frombuffer(self._shm.buf, dtype=np.uint8, count=total)
+        self._host = torch.from_numpy(self._np)
+        self._stage = self._events = None
+        self._staged = [-1] * self.slots  # the step whose rows sit in staging slot k and are not yet in the shared buffer
+        if device is not None:
+            from . import _lib
+            with _lib.on_device(device):
+                self._stage = [torch.empty(self._stage_bytes, dtype=torch.uint8, pin_memory=True) for _ in range(self.slots)]
+                self._events = [_lib.HipEvent(_lib.hipEventDisableTiming) for _ in range(self.slots)]  # host-visible release
+
+    def view(self, step: int, name: str) -> torch.Tensor:
+        """Host tensor ``(batch, *per_image_shape)`` of section ``name`` for ``step`` (slot ``step % slots`` of the shared
+        buffer, the same memory in every rank)."""
+        off, shape, dtype, row, _ = self._layout[name]
+        start = (step % self.slots) * self.slot_bytes + off
+        return self._host[start:start + row * self.batch].view(dtype).view((self.batch,) + shape)
+
+    def write_step(self, step: int, outputs, stream: Optional[int] = None) -> None:
+        """Put this rank's rows of every section for ``step`` on their way: ``outputs[name]`` is the local
+        ``(hi-lo, *per_image_shape)`` tensor.  Returns at once on a GPU (copy kernels + one event on ``stream``)."""
+        n = self.hi - self.lo
+        k = step % self.slots
+        if self._staged[k] >= 0:
+            self._publish(k)  # the step that used this staging slot `slots` steps ago: long complete in a running loop
+        for name, (off, shape, dtype, row, loc) in self._layout.items():
+            local = outputs[name]
+            if local.numel() != n * (row // local.element_size()) or local.dtype != dtype or not local.is_contiguous():
+                raise ValueError(f"{name}: expected a contiguous {(n,) + shape} {dtype} tensor, got {tuple(local.shape)} {local.dtype}")
+            if n == 0:
+                continue
+            if self.device is None:
+                start = k * self.slot_bytes + off + self.lo * row
+                self._host[start:start + n * row].copy_(local.reshape(-1).view(torch.uint8))
+            else:
+                from . import _lib
+                if stream is None:
+                    stream = _lib.stream_ptr(self.device)
+                with _lib.on_device(self.device):
+                    _lib.check(_lib.lib().frcnn_gather_copy(local.data_ptr(), self._stage[k].data_ptr() + loc, n * row, stream))
+        if self.device is not None and n > 0:
+            self._events[k].record(stream)
+            self._staged[k] = step
+
+    def _publish(self, k: int) -> None:
+        self._events[k].synchronize()
+        n = self.hi - self.lo
+        for off, shape, dtype, row, loc in self._layout.values():
+            start = k * self.slot_bytes + off + self.lo * row
+            self._host[start:start + n * row].copy_(self._stage[k][loc:loc + n * row])
+        self._staged[k] = -1
+
+    def flush(self) -> None:
+        """Block until every step written so far is in the shared buffer (oldest first)."""
+        for k in sorted((k for k in range(self.slots) if self._staged[k] >= 0), key=lambda k: self._staged[k]):
+            self._publish(k)
+
+    def close(self) -> None:
+        """Unmap; the creating rank removes the shared memory.  Idempotent."""
+        shm = getattr(self, "_shm", None)
+        if shm is None:
+            return
+        self._host = None
+        self._np = None
+        self._stage = None
+        try:
+            shm.close()
+        except BufferError:
+            pass
+        if self.rank == 0:
+            try:
+                shm.unlink()
+            except FileNotFoundError:
+                pass
+        self._shm = None
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -37,23 +37,38 @@ def timeit(fn, iters, warmup=5):
     return e0.elapsed_time(e1) / iters  # ms
 
 
-def rois_for(B, G, K, R, seed=0, mode="inference"):
+SETS = 1  # --sets: input sets rotated through the iterations (1 = the same tensors every time, i.e. cache-warm inputs)
+
+
+def rotating(make, n=None):
+    """`make(k)` builds input set k; returns a function that hands out the sets in turn."""
+    sets = [make(k) for k in range(n or SETS)]
+    state = {"i": 0}
+
+    def nxt():
+        state["i"] += 1
+        return sets[state["i"] % len(sets)]
+    return nxt
+
+
+def rois_for(B, G, K, R, seed=0, mode="inference", delta_scale=1.0):
     hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G, pre_nms_topn=K)
     hp["train_nms_topn" if mode == "training" else "test_nms_topn"] = R
     anchors = pkg.bbox_utils.generate_anchors(hp)
     d, s = synth.rpn_outputs(seed, B, G)
     layer = pkg.faster_rcnn.RoIBBox(anchors, mode, hp)
-    return hp, anchors, torch.as_tensor(d).cuda(), torch.as_tensor(s).cuda(), layer
+    return hp, anchors, torch.as_tensor(d * np.float32(delta_scale)).cuda(), torch.as_tensor(s).cuda(), layer
 
 
 def case_crop(name, B, G, C, R, K, iters):
     hp, anchors, d, s, layer = rois_for(B, G, K, R, mode="training")
     rois = layer([d, s])
-    fm = torch.as_tensor(synth.feature_map(0, B, G, C)).cuda()
+    fm0 = torch.as_tensor(synth.feature_map(0, B, G, C)).cuda()
+    nxt = rotating(lambda k: fm0 if k == 0 else torch.roll(fm0, k, 0).contiguous())
     pool = pkg.faster_rcnn.RoIPooling(hp)
-    ms = timeit(lambda: pool([fm, rois]), iters)
+    ms = timeit(lambda: pool([nxt(), rois]), iters)
     nbytes = B * (R * 49 * C * 4 + G * G * C * 4 + R * 20)
-    return dict(case=name, kernel="crop_resize_kernel<4>", ms=ms, bytes=nbytes, B=B, R=R, C=C, G=G)
+    return dict(case=name, kernel="crop_resize_*", ms=ms, bytes=nbytes, B=B, R=R, C=C, G=G, input_sets=SETS)
 
 
 def case_iou_map(name, B, G, M, iters):
@@ -80,12 +95,27 @@ def case_targets(name, B, G, M, iters):
                 images_per_s=B / (ms * 1e-3))
 
 
-def case_roi_bbox(name, B, G, K, R, iters, mode="inference"):
-    hp, anchors, d, s, layer = rois_for(B, G, K, R, mode=mode)
+def case_roi_bbox(name, B, G, K, R, iters, mode="inference", delta_scale=1.0):
+    """delta_scale < 1: clustered proposals (deltas shrunk, so the decoded boxes stay close to their anchors and overlap
+    heavily): NMS consumes far more candidates before R boxes are kept -- the lazy kernel's slow regime."""
+    hp, anchors, d, s, layer = rois_for(B, G, K, R, mode=mode, delta_scale=delta_scale)
     ms = timeit(lambda: layer([d, s]), iters)
     N = anchors.shape[0]
     return dict(case=name, kernel="proposal_kernel", ms=ms, bytes=B * (N * 4 + K * 16 + R * 16), B=B, N=N, K=K, R=R,
-                images_per_s=B / (ms * 1e-3))
+                delta_scale=delta_scale, images_per_s=B / (ms * 1e-3))
+
+
+def case_roi_delta(name, B, R, M, L, iters):
+    hp = pkg.train_utils.get_hyper_params("vgg16")
+    hp["total_labels"] = L
+    rng = np.random.default_rng(3)
+    rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+    gt, lab = synth.gt_boxes(0, B, M)
+    rois, gt, lab = (torch.as_tensor(a).cuda() for a in (rois, gt, lab))
+    layer = pkg.faster_rcnn.RoIDelta(hp)
+    ms = timeit(lambda: layer([rois, gt, lab], seed=1), iters)
+    return dict(case=name, kernel="iou_reduce_kernel + roi_delta_kernel", ms=ms, bytes=B * (R * 16 + M * 20 + R * L * 20), B=B, R=R,
+                M=M, L=L, images_per_s=B / (ms * 1e-3))
 
 
 def case_decoder(name, B, R, L, iters):
@@ -109,6 +139,10 @@ CASES = {
     "targets_cfg4": lambda it: case_targets("targets_cfg4", 64, 32, 100, it),
     "targets_cfg4_shard": lambda it: case_targets("targets_cfg4_shard", 8, 32, 100, it),
     "roi_bbox_cfg2": lambda it: case_roi_bbox("roi_bbox_cfg2", 16, 32, 6000, 300, it),
+    "roi_bbox_cfg2_clustered": lambda it: case_roi_bbox("roi_bbox_cfg2_clustered", 16, 32, 6000, 300, it, delta_scale=0.05),
+    "roi_bbox_cfg3_shard8": lambda it: case_roi_bbox("roi_bbox_cfg3_shard8", 8, 31, 6000, 2000, it, mode="training"),
+    "roi_delta_cfg3_shard8": lambda it: case_roi_delta("roi_delta_cfg3_shard8", 8, 2000, 32, 21, it),
+    "crop_cfg3_shard8": lambda it: case_crop("crop_cfg3_shard8", 8, 31, 512, 2000, 6000, it),
     "roi_bbox_cfg3": lambda it: case_roi_bbox("roi_bbox_cfg3", 16, 31, 6000, 2000, it, mode="training"),
     "roi_bbox_cfg5": lambda it: case_roi_bbox("roi_bbox_cfg5", 16, 63, 12000, 300, it),
     "decoder_cfg2": lambda it: case_decoder("decoder_cfg2", 16, 300, 21, it),
@@ -119,7 +153,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--sets", type=int, default=1, help="input sets rotated through the iterations of the crop cases")
     args = ap.parse_args()
+    global SETS
+    SETS = max(1, args.sets)
     names = [n for n in args.only.split(",") if n] or list(CASES)
     for n in names:
         r = CASES[n](args.iters)
