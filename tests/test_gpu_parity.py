@@ -190,11 +190,15 @@ def test_iou_map_range_stress(pkg, kind):
     assert_bits(pkg.bbox_utils.generate_iou_map(dev(bb[0]), dev(gt)), want1, f"iou_map {kind} (shared boxes)")
 
 
+@pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("kind", ["plain", "slivers", "grid", "extremes", "rough"])
-def test_iou_map_reduce_range_stress(pkg, kind):
+def test_iou_map_reduce_range_stress(pkg, knobs, kind, split):
     """frcnn_iou_map_reduce (the fused reductions of utils/train_utils.py:177-179) through the C ABI on the same inputs:
-    row max / first argmax / first column argmax must equal those of the oracle's materialised map."""
+    row max / first argmax / first column argmax must equal those of the oracle's materialised map -- with one box per
+    lane walking every gt, and with the small-batch form (64 boxes x 4 gt quarters per workgroup)."""
     from tf_faster_rcnn_amd import _lib
+
+    knobs.setenv("FRCNN_IOU_REDUCE_SPLIT", split)
 
     rng = np.random.default_rng({"plain": 11, "slivers": 12, "grid": 13, "extremes": 14, "rough": 15}[kind])
     B, N, M = 3, 1500, 37
@@ -223,6 +227,35 @@ def test_iou_map_reduce_range_stress(pkg, kind):
     assert_bits(mx, want_max, f"iou_map_reduce {kind}: row max")
     assert_bits(ar, want_row, f"iou_map_reduce {kind}: row argmax")
     assert_bits(ac, want_col, f"iou_map_reduce {kind}: column argmax")
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_iou_map_reduce_ties_and_ragged_shapes(pkg, knobs, split):
+    """Equal maxima (the earliest gt / the lowest box index wins), gt counts that do not divide by four, fewer gts than
+    quarters, box counts that are not a multiple of the workgroup: both forms of the fused reductions."""
+    from tf_faster_rcnn_amd import _lib
+
+    knobs.setenv("FRCNN_IOU_REDUCE_SPLIT", split)
+    rng = np.random.default_rng(5)
+    lib = _lib.lib()
+    for B, N, M in ((2, 130, 9), (1, 64, 3), (3, 257, 50), (2, 1000, 1), (1, 77, 101)):
+        gt = np.sort(rng.random((B, M, 2, 2)).astype(np.float32), axis=2).reshape(B, M, 4)
+        gt[:, M // 2:] = gt[:, : M - M // 2]      # duplicated gts: equal IoUs in different quarters
+        bb = np.sort(rng.random((B, N, 2, 2)).astype(np.float32), axis=2).reshape(B, N, 4)
+        bb[:, N // 3: 2 * (N // 3)] = bb[:, : N // 3]  # duplicated boxes: equal column maxima
+        iou = oracle.generate_iou_map(bb, gt)
+        filled = np.where(np.isnan(iou), -np.inf, iou)
+        mx = torch.empty((B, N), dtype=torch.float32, device="cuda")
+        ar = torch.empty((B, N), dtype=torch.int32, device="cuda")
+        ac = torch.empty((B, M), dtype=torch.int32, device="cuda")
+        ws = torch.empty(max(1, lib.frcnn_iou_reduce_workspace_bytes(B, N, M)), dtype=torch.uint8, device="cuda")
+        d_bb, d_gt = dev(bb), dev(gt)
+        _lib.check(lib.frcnn_iou_map_reduce(d_bb.data_ptr(), 1, d_gt.data_ptr(), B, N, M, mx.data_ptr(), ar.data_ptr(),
+                                            ac.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert_bits(mx, filled.max(axis=2).astype(np.float32), f"row max B={B} N={N} M={M}")
+        assert_bits(ar, filled.argmax(axis=2).astype(np.int32), f"row argmax B={B} N={N} M={M}")
+        assert_bits(ac, filled.argmax(axis=1).astype(np.int32), f"column argmax B={B} N={N} M={M}")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -582,6 +615,34 @@ def test_rpn_targets(pkg, B, G, M):
     assert (nz <= (l2 == 1)).all()
 
 
+@pytest.mark.parametrize("total_pos,total_neg,bad_ints", [(128, 128, False), (4, 6, False), (128, 128, True), (3, 500, True),
+                                                         (0, 20, False), (20000, 20000, False)])
+def test_rpn_targets_selection_regimes(pkg, total_pos, total_neg, bad_ints):
+    """The sampling of calculate_rpn_actual_outputs in every regime of the selection: fewer candidates than the quota (the
+    radix selection is skipped), more candidates than the quota, quotas of 0 and beyond N, and out-of-contract random
+    integers (<= 0 on masked anchors: they rank among the unmasked ones, so the shortcut must not be taken)."""
+    B, G, M = 4, 16, 12
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, total_pos_bboxes=total_pos, total_neg_bboxes=total_neg)
+    anchors = oracle.generate_anchors(hp)
+    N = anchors.shape[0]
+    gt, labels = synth.gt_boxes(9, B, M)
+    gt[0, :3] = anchors[[100, 700, 1500]]  # exact anchor hits: IoU 1 positives besides the forced ones
+    labels[0, :3] = 1
+    rp, rn = synth.sampling_ints(9, B, N, max(total_pos, 1), max(total_neg, 1))
+    if bad_ints:
+        rng = np.random.default_rng(2)
+        rp[rng.random(rp.shape) < 0.3] = 0
+        rp[rng.random(rp.shape) < 0.1] = -7
+        rn[rng.random(rn.shape) < 0.3] = 0
+        rn[rng.random(rn.shape) < 0.1] = -2
+    got_d, got_l = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp,
+                                                                random_masks=(dev(rp), dev(rn)))
+    want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
+    assert_bits(got_l, want_l, "rpn labels")
+    assert_bits(got_d, want_d, "rpn deltas")
+
+
 # ------------------------------------------------------------------------------------------------
 # RoIDelta (second-stage training targets)
 # ------------------------------------------------------------------------------------------------
@@ -719,6 +780,53 @@ def test_generators_prefetch_targets_on_side_stream(pkg):
     assert_bits(deltas, items[0][0][3].cpu().numpy(), "rpn_generator deltas")
     with pytest.raises(ValueError):
         next(pkg.train_utils.rpn_generator([], anchors, hp))
+
+
+@pytest.mark.parametrize("prefetch", [0, 1, 2])
+@pytest.mark.parametrize("carrier", ["callable", "dataset"])
+def test_generators_match_oracle_with_injected_sampling_integers(pkg, prefetch, carrier):
+    """utils/train_utils.py:91-136 against the ORACLE: the sampling integers of every batch are supplied (by a per-batch
+    callable, or riding with the dataset item), so the feeders' targets are comparable with
+    oracle.calculate_rpn_actual_outputs bit for bit -- over more than two passes of the dataset, at prefetch 0 / 1 / 2."""
+    import itertools
+
+    G, B, M = 16, 3, 9
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G)
+    anchors = oracle.generate_anchors(hp)
+    N = anchors.shape[0]
+    raw = [synth.gt_boxes(40 + i, B, M) for i in range(3)]
+    ints = {i: synth.sampling_ints(500 + i, B, N) for i in range(12)}  # a different draw for every batch, passes included
+    if carrier == "callable":
+        data = [(torch.full((B, 2), float(i)), dev(gt), dev(lab)) for i, (gt, lab) in enumerate(raw)]
+        kw = dict(random_masks=lambda i, b, n: (assert_eq((b, n), (B, N)), ints[i])[1])
+    else:
+        class Passes:  # a re-iterable whose items carry their integers (host arrays: the feeder moves them to the device)
+            def __init__(self):
+                self.count = 0
+
+            def __iter__(self):
+                for i, (gt, lab) in enumerate(raw):
+                    rp, rn = ints[self.count]
+                    self.count += 1
+                    yield torch.full((B, 2), float(i)), gt, lab, rp, rn
+        data, kw = Passes(), {}
+    gen = pkg.train_utils.faster_rcnn_generator(data, dev(anchors), hp, prefetch=prefetch, **kw)
+    torch.cuda._sleep(3_000_000)  # the consumer's stream is busy: hand-over must still order the targets before their use
+    for i, ((img, gt, lab, deltas, labels), empty) in enumerate(itertools.islice(gen, 7)):
+        assert empty == () and float(img[0, 0]) == float(i % 3)
+        want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, raw[i % 3][0], raw[i % 3][1], hp, ints[i])
+        assert_bits(labels, want_l, f"{carrier} prefetch={prefetch} batch {i} labels")
+        assert_bits(deltas, want_d, f"{carrier} prefetch={prefetch} batch {i} deltas")
+        assert_bits(gt, raw[i % 3][0], "gt boxes handed through")
+    if carrier == "callable":
+        img, (deltas, labels) = next(pkg.train_utils.rpn_generator(data, dev(anchors), hp, prefetch=prefetch, **kw))
+        want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, raw[0][0], raw[0][1], hp, ints[0])
+        assert_bits(labels, want_l, "rpn_generator labels")
+        assert_bits(deltas, want_d, "rpn_generator deltas")
+
+
+def assert_eq(a, b):
+    assert a == b, (a, b)
 
 
 def test_config1_batch1_full_path(pkg):

@@ -239,10 +239,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 // One box against every gt of its image (row max / first argmax in registers, column keys merged in LDS).
 template <bool NONAN>
-__device__ __forceinline__ void reduce_row(const float *lds, int Mp, int M, float4 bx, float barea, bool live, int n,
+__device__ __forceinline__ void reduce_row(const float *lds, int Mp, int m0, int m1, float4 bx, float barea, bool live, int n,
                                            bool want_cols, unsigned long long *colk, float &best, float &mx, int &am) {
   const unsigned long long live_mask = ballot64(live);
-  for (int m = 0; m < M; ++m) {
+  for (int m = m0; m < m1; ++m) {
     float inter, uni;
     iou_terms<NONAN>(bx.x, bx.y, bx.z, bx.w, barea, lds[m], lds[Mp + m], lds[2 * Mp + m], lds[3 * Mp + m], lds[4 * Mp + m],
                      inter, uni);
@@ -303,15 +303,78 @@ __global__ __launch_bounds__(256) void iou_reduce_kernel(const float *__restrict
   float best = -3.402823466e+38f, mx = -3.402823466e+38f;
   int am = 0;
   if (!gt_nan && ballot64(barea != barea) == 0ull)  // wave-uniform: no NaN coordinate in this wave's boxes or the gts
-    reduce_row<true>(lds, Mp, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
+    reduce_row<true>(lds, Mp, 0, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
   else
-    reduce_row<false>(lds, Mp, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
+    reduce_row<false>(lds, Mp, 0, M, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
   if (live) {
     if (max_iou) max_iou[(long long)b * N + n] = mx;
     if (argmax_row) argmax_row[(long long)b * N + n] = am;
   }
   if (col_keys) {
     __syncthreads();
+    for (int m = threadIdx.x; m < M; m += 256) {
+      const unsigned long long k = colk[m];
+      if (k != 0ull) atomicMax(&col_keys[(long long)b * M + m], k);
+    }
+  }
+}
+
+// The same reductions for SMALL batches (a per-GPU shard of 8 images is 288 workgroups of the kernel above: one wave per
+// SIMD, each walking all M gts in one dependent chain -- 46 us at config 4's shard, latency bound).  Here a workgroup is
+// 64 boxes x 4 gt quarters: wave q walks gts [q*M/4, (q+1)*M/4) for the same 64 boxes, so four times as many waves share
+// the chain, and the per-box partial results are merged in LDS in quarter order (strict '>': the earliest gt among equal
+// maxima wins, as in one sweep).  grid: (ceil(N/64), B); block 256.
+// LDS: 5*Mp floats of gt + M uint64 column keys + 3 * 256 words of partial results.
+__global__ __launch_bounds__(256) void iou_reduce_split_kernel(const float *__restrict__ bboxes, long long bboxes_stride_b,
+                                                               const float *__restrict__ gt, int N, int M,
+                                                               float *__restrict__ max_iou, int *__restrict__ argmax_row,
+                                                               unsigned long long *__restrict__ col_keys) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int b = blockIdx.y;
+  const int Mp = (M + 3) & ~3;
+  unsigned long long *colk = reinterpret_cast<unsigned long long *>(lds + 5 * Mp);
+  float *part = reinterpret_cast<float *>(colk + (M > 0 ? M : 1));  // [3][256]: best, mx, am
+  if (col_keys)
+    for (int m = threadIdx.x; m < M; m += 256) colk[m] = 0ull;
+  const bool gt_nan = stage_gt(lds, gt + (long long)b * M * 4, M, Mp);  // includes the barrier
+
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const bool live = n < N;
+  float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) bx = *reinterpret_cast<const float4 *>(bboxes + (long long)b * bboxes_stride_b + (long long)n * 4);
+  const float bh = bx.z - bx.x;
+  const float bw = bx.w - bx.y;
+  const float barea = bh * bw;
+  const int per = (M + 3) >> 2;
+  const int m0 = (q * per < M) ? q * per : M;
+  const int m1 = (m0 + per < M) ? m0 + per : M;
+  float best = -3.402823466e+38f, mx = -3.402823466e+38f;
+  int am = 0;
+  if (!gt_nan && ballot64(barea != barea) == 0ull)  // the four waves hold the same boxes: the same decision in all of them
+    reduce_row<true>(lds, Mp, m0, m1, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
+  else
+    reduce_row<false>(lds, Mp, m0, m1, bx, barea, live, n, col_keys != nullptr, colk, best, mx, am);
+  part[threadIdx.x] = best;
+  part[256 + threadIdx.x] = mx;
+  part[512 + threadIdx.x] = __int_as_float(am);
+  __syncthreads();
+  if (q == 0 && live) {
+    // quarter 0 is this wave's own (best, mx, am); later quarters only win with a strictly larger value
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float bk = part[k * 64 + lane];
+      const float mk = part[256 + k * 64 + lane];
+      if (bk > best) {
+        best = bk;
+        am = __float_as_int(part[512 + k * 64 + lane]);
+      }
+      if (mk > mx) mx = mk;
+    }
+    if (max_iou) max_iou[(long long)b * N + n] = mx;
+    if (argmax_row) argmax_row[(long long)b * N + n] = am;
+  }
+  if (col_keys) {
     for (int m = threadIdx.x; m < M; m += 256) {
       const unsigned long long k = colk[m];
       if (k != 0ull) atomicMax(&col_keys[(long long)b * M + m], k);
@@ -396,8 +459,16 @@ int frcnn_iou_map_reduce(const float *bboxes, int bboxes_batched, const float *g
     const size_t lds_bytes = (size_t)5 * Mp * sizeof(float) + (size_t)(M > 0 ? M : 1) * sizeof(unsigned long long);
     dim3 grid((unsigned)((N + 255) / 256), (unsigned)B), block(256);
     const long long stride = bboxes_batched ? (long long)N * 4 : 0;
-    hipLaunchKernelGGL(iou_reduce_kernel, grid, block, lds_bytes, s, bboxes, stride, gt_boxes, N, M, max_iou,
-                       argmax_row, keys);
+    // 64 boxes x 4 gt quarters per workgroup whenever there are gts to split (measured at config 4: 8 images 46 -> 20 us,
+    // 64 images 104 -> 83 us); FRCNN_IOU_REDUCE_SPLIT = 0 | 1 forces one form
+    const bool split = knob(kKnobIouReduceSplit, M >= 8 ? 1 : 0) != 0 && M > 0 &&
+                       lds_bytes + 3 * 256 * 4 <= 48 * 1024;
+    if (split)
+      hipLaunchKernelGGL(iou_reduce_split_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)B), block, lds_bytes + 3 * 256 * 4, s,
+                         bboxes, stride, gt_boxes, N, M, max_iou, argmax_row, keys);
+    else
+      hipLaunchKernelGGL(iou_reduce_kernel, grid, block, lds_bytes, s, bboxes, stride, gt_boxes, N, M, max_iou,
+                         argmax_row, keys);
     int rc = check_launch("iou_map_reduce");
     if (rc) return rc;
   }

@@ -43,25 +43,75 @@ __device__ __forceinline__ int draw_int(uint64_t seed, uint32_t stream, int b, i
 // for every n < N with in == (rank of n in the descending key order, ties by index) < S.
 // hist: 256 uint32 in LDS; misc: 8 ints in LDS; wsum: kTNW ints in LDS; kcache: N uint32 of LDS or NULL -- with it
 // keyf is evaluated once per element (its inputs usually sit in global memory) and the passes read LDS.
-template <class KeyF, class EmitF>
+struct NoMask {};
+
+// maskf (optional, with kcache): maskf(n) = the element's mask bit, for the shortcut below.  The reference keeps the
+// masked elements whose rank in the descending order of key = mask * random is below S.  If no more than S keys are
+// positive, every positive key has rank < S; and if besides no MASKED element has a key <= 0 (random integers are >= 1 by
+// contract, but out-of-contract ones are honoured), the elements with key <= 0 are all unmasked and dropped by the caller
+// whatever their rank: the radix selection is skipped.  This is the usual case for the positives of target assignment
+// (a few dozen anchors above the IoU threshold against S = 128).
+template <class KeyF, class EmitF, class MaskF = NoMask>
 __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t *hist, int *misc, int *wsum,
-                                               EmitF emit, uint32_t *kcache = nullptr) {
+                                               EmitF emit, uint32_t *kcache = nullptr, MaskF maskf = MaskF()) {
+  constexpr bool kHasMask = !__is_same(MaskF, NoMask);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (S <= 0 || S >= N) {  // uniform: nobody / everybody has rank < S
     const bool in = (S >= N) && (S > 0);
     for (int n = tid; n < N; n += kTNT) emit(n, in);
     return;
   }
+  uint32_t vary = 0xFFFFFFFFu, common = 0u;  // key bits that differ between elements / the value of those that do not
   if (kcache) {
+    if (tid == 0) {
+      misc[4] = 0;
+      misc[5] = -1;
+    }
     __syncthreads();  // the cache may still be read by a previous selection
-    for (int n = tid; n < N; n += kTNT) kcache[n] = inv_key(keyf(n));
-    __syncthreads();
+    int npos = 0, bad = 0;
+    uint32_t orv = 0u, andv = 0xFFFFFFFFu;
+    for (int n = tid; n < N; n += kTNT) {
+      const int k = keyf(n);
+      const uint32_t ik = inv_key(k);
+      kcache[n] = ik;
+      orv |= ik;
+      andv &= ik;
+      npos += (k > 0);
+      if constexpr (kHasMask) bad |= (k <= 0) && maskf(n);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      orv |= (uint32_t)__shfl_xor((int)orv, off, 64);
+      andv &= (uint32_t)__shfl_xor((int)andv, off, 64);
+    }
+    if (lane == 0) {
+      atomicOr(reinterpret_cast<unsigned int *>(&misc[4]), orv);
+      atomicAnd(reinterpret_cast<unsigned int *>(&misc[5]), andv);
+    }
+    if constexpr (kHasMask) {
+      int total;
+      (void)block_excl_scan(npos + (bad << 20), wsum, total);  // N < 2^20 (kMaxTargetsN), 1024 flags < 2^11; has the barriers
+      if ((total >> 20) == 0 && (total & 0xFFFFF) <= S) {      // block-uniform
+        for (int n = tid; n < N; n += kTNT) emit(n, kcache[n] < inv_key(0));
+        return;
+      }
+    } else {
+      __syncthreads();
+    }
+    // Keys are mask * (random integer below a few thousand): their upper bytes are the same for every element, and a
+    // radix pass over a byte in which no two keys differ selects nothing -- it is skipped (2 passes instead of 4).
+    common = (uint32_t)misc[4];
+    vary = common ^ (uint32_t)misc[5];
   }
   auto key_at = [&](int n) -> uint32_t { return kcache ? kcache[n] : inv_key(keyf(n)); };
   uint32_t prefix = 0;
   int need = S;
   for (int pass = 3; pass >= 0; --pass) {
     const int shift = pass * 8;
+    if (((vary >> shift) & 255u) == 0u) {  // block-uniform: every key carries the same digit here
+      prefix = (prefix << 8) | ((common >> shift) & 255u);
+      continue;
+    }
     __syncthreads();
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
@@ -190,7 +240,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
       atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
       atomicAdd(&s_pos_count, 1);
     }
-  }, kcache);
+  }, kcache, [&](int n) -> bool { return (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u); });
   __syncthreads();
   FRCNN_STAMP(32);
   // :190-191
@@ -205,7 +255,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   select_largest(neg_key, N, neg_count, hist, misc, wsum, [&](int n, bool in) {
     const bool msk = (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u);
     if (msk && in) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
-  });
+  }, kcache, [&](int n) -> bool { return (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u); });
   __syncthreads();
 
   FRCNN_STAMP(33);

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import math
 from collections import deque
-from typing import Any, Dict, Iterable, Iterator, Optional, Sequence, Tuple
+from typing import Any, Callable, Dict, Iterable, Iterator, Optional, Sequence, Tuple
 
 import torch
 
@@ -164,33 +164,53 @@ def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, 
 
 
 
-def _rpn_target_batches(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.Tensor, hyper_params: HyperParams,
-                        prefetch: int, seed: Optional[int]) -> Iterator[Tuple[torch.Tensor, ...]]:
+RandomMasks = Callable[[int, int, int], Tuple[Any, Any]]
+
+
+def _rpn_target_batches(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tensor, hyper_params: HyperParams,
+                        prefetch: int, seed: Optional[int],
+                        random_masks: Optional[RandomMasks] = None) -> Iterator[Tuple[torch.Tensor, ...]]:
     """Endless ``(img, gt_boxes, gt_labels, bbox_deltas, bbox_labels)`` stream over ``dataset`` (re-iterated forever, as
     the reference's ``while True``).  Target assignment for up to ``prefetch`` batches ahead is enqueued on a side HIP
     stream, off the consumer's stream (the reference computes it eagerly on the Python feeder thread,
-    ``utils/train_utils.py:108-112``); the consumer's current stream waits on the batch's event when it is handed over."""
+    ``utils/train_utils.py:108-112``); the consumer's current stream waits on the batch's event when it is handed over.
+
+    The sampling integers of a batch (the reference draws them from TF's unseeded RNG, ``utils/train_utils.py:82-83``)
+    come, in this order of precedence, from the dataset item itself when it is a 5-tuple
+    ``(img, gt_boxes, gt_labels, rnd_pos, rnd_neg)``, from ``random_masks(batch_index, batch, total_anchors)``, or from
+    the in-kernel draw seeded with ``seed + batch_index``."""
     anchors_t = _lib.device_tensor(anchors, torch.float32)
     device = anchors_t.device
+    N = anchors_t.shape[0]
     side = torch.cuda.Stream(device)
     pending: deque = deque()
     counter = 0
     while True:
         produced = False
-        for img, gt_boxes, gt_labels in dataset:
+        for item in dataset:
             produced = True
+            if len(item) == 5:
+                img, gt_boxes, gt_labels, rnd_pos, rnd_neg = item
+                masks: Optional[Tuple[Any, Any]] = (rnd_pos, rnd_neg)
+            else:
+                img, gt_boxes, gt_labels = item
+                masks = None
             gt_t = _lib.device_tensor(gt_boxes, torch.float32, device)
             lab_t = _lib.device_tensor(gt_labels, torch.int32, device)
+            if masks is None and random_masks is not None:
+                masks = random_masks(counter, gt_t.shape[0], N)
+            if masks is not None:  # brought to the device on the caller's stream, like the gt tensors
+                masks = (_lib.device_tensor(masks[0], torch.int32, device), _lib.device_tensor(masks[1], torch.int32, device))
             ready = _lib.HipEvent()
             ready.record(torch.cuda.current_stream(device).cuda_stream)  # the gt tensors come from the caller's stream
             ready.wait(side.cuda_stream)
             with torch.cuda.stream(side):
-                deltas, labels = calculate_rpn_actual_outputs(anchors_t, gt_t, lab_t, hyper_params,
+                deltas, labels = calculate_rpn_actual_outputs(anchors_t, gt_t, lab_t, hyper_params, random_masks=masks,
                                                               seed=None if seed is None else seed + counter)
             done = _lib.HipEvent()
             done.record(side.cuda_stream)
             counter += 1
-            pending.append((img, gt_t, lab_t, deltas, labels, done))
+            pending.append((img, gt_t, lab_t, deltas, labels, done, masks))
             if len(pending) > prefetch:
                 yield _hand_over(pending.popleft(), device)
         if not produced:
@@ -199,26 +219,35 @@ def _rpn_target_batches(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.
 
 
 def _hand_over(item: Tuple[Any, ...], device: torch.device) -> Tuple[torch.Tensor, ...]:
-    img, gt_t, lab_t, deltas, labels, done = item
+    img, gt_t, lab_t, deltas, labels, done, masks = item
     cur = torch.cuda.current_stream(device)
     done.wait(cur.cuda_stream)
     deltas.record_stream(cur)  # allocated on the side stream, consumed on the caller's
     labels.record_stream(cur)
+    if masks is not None:  # allocated on the caller's stream, read on the side stream: safe to free once `done` has passed
+        masks[0].record_stream(cur)
+        masks[1].record_stream(cur)
     return img, gt_t, lab_t, deltas, labels
 
 
-def faster_rcnn_generator(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.Tensor, hyper_params: HyperParams,
-                          prefetch: int = 1, seed: Optional[int] = None) -> Iterator[Tuple[Tuple[torch.Tensor, ...], Tuple[()]]]:
+def faster_rcnn_generator(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tensor, hyper_params: HyperParams,
+                          prefetch: int = 1, seed: Optional[int] = None,
+                          random_masks: Optional[RandomMasks] = None) -> Iterator[Tuple[Tuple[torch.Tensor, ...], Tuple[()]]]:
     """Yield ``((img, gt_boxes, gt_labels, bbox_deltas, bbox_labels), ())`` forever.  Mirrors reference
     ``utils/train_utils.py:91-112``; ``dataset`` is any re-iterable of padded ``(img, gt_boxes, gt_labels)`` batches.
-    Extra arguments: ``prefetch`` batches of targets kept in flight on a side stream; ``seed`` makes the sampling
-    reproducible (batch ``i`` uses ``seed + i``)."""
-    for batch in _rpn_target_batches(dataset, anchors, hyper_params, max(0, int(prefetch)), seed):
+    Extra arguments: ``prefetch`` batches of targets kept in flight on a side stream; ``seed`` makes the in-kernel sampling
+    reproducible (batch ``i`` uses ``seed + i``); ``random_masks(i, batch, total_anchors) -> (pos, neg)`` supplies the
+    sampling integers of batch ``i`` instead (int32 ``(batch, total_anchors)`` each), as do dataset items that carry them
+    as a 4th and 5th element."""
+    for batch in _rpn_target_batches(dataset, anchors, hyper_params, max(0, int(prefetch)), seed, random_masks):
         yield batch, ()
 
 
-def rpn_generator(dataset: Iterable[Tuple[Any, Any, Any]], anchors: torch.Tensor, hyper_params: HyperParams,
-                  prefetch: int = 1, seed: Optional[int] = None) -> Iterator[Tuple[Any, Tuple[torch.Tensor, torch.Tensor]]]:
-    """Yield ``(img, (bbox_deltas, bbox_labels))`` forever.  Mirrors reference ``utils/train_utils.py:115-136``."""
-    for img, _, _, deltas, labels in _rpn_target_batches(dataset, anchors, hyper_params, max(0, int(prefetch)), seed):
+def rpn_generator(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tensor, hyper_params: HyperParams,
+                  prefetch: int = 1, seed: Optional[int] = None,
+                  random_masks: Optional[RandomMasks] = None) -> Iterator[Tuple[Any, Tuple[torch.Tensor, torch.Tensor]]]:
+    """Yield ``(img, (bbox_deltas, bbox_labels))`` forever.  Mirrors reference ``utils/train_utils.py:115-136``; extra
+    arguments as ``faster_rcnn_generator``."""
+    for img, _, _, deltas, labels in _rpn_target_batches(dataset, anchors, hyper_params, max(0, int(prefetch)), seed,
+                                                         random_masks):
         yield img, (deltas, labels)

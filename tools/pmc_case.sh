@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python3 $GRAFT_REPO_ROOT/tools/bench_kernels.py --only $kase --iters 20 "$@" > $out/trace.log 2>&1
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_64B_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
   timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $out/p$i -o p$i -- python3 $GRAFT_REPO_ROOT/tools/bench_kernels.py --only $kase --iters 5 "$@" > $out/p$i.log 2>&1
 done
