@@ -476,10 +476,8 @@ def main() -> int:
         pin = pinned if pin is None else pin
         if sh:
             sh.write_step(i, outs, cur)
-        elif pin:
-            for name, dst in pin.items():
-                src = outs[name]
-                pkg._lib.check(pkg._lib.lib().frcnn_gather_copy(src.data_ptr(), dst.data_ptr(), src.numel() * 4, cur))
+        elif pin:  # the host gather of the small outputs: one copy kernel for all of them
+            pkg._lib.gather_copy_multi([(outs[name].data_ptr(), dst.data_ptr(), outs[name].numel() * 4) for name, dst in pin.items()], cur)
         return outs
 
     pipe = None

@@ -225,6 +225,10 @@ int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_
  * reference, which is single-device; Keras' predict() returns host arrays: faster_rcnn_predictor.py:56).  A kernel on
  * `stream`, not a copy-engine transfer: it orders like any other stage.  Both pointers 16-byte aligned. */
 int frcnn_gather_copy(const void *src, void *dst, size_t bytes, frcnn_stream_t stream);
+/* The same for n (0..8) separate tensors in ONE launch: srcs / dsts / bytes are HOST arrays of n entries; every segment
+ * 16-byte aligned and a multiple of 16 bytes.  (RoIs, boxes, labels and scores of a batch are four tensors.) */
+int frcnn_gather_copy_multi(const void *const *srcs, void *const *dsts, const size_t *bytes, int n,
+                            frcnn_stream_t stream);
 
 #ifdef __cplusplus
 }

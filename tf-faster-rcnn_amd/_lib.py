@@ -55,6 +55,7 @@ SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
     "frcnn_decoder": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_decoder_multi": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_gather_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "frcnn_gather_copy_multi": (_i, [_vp, _vp, _vp, _i, _vp]),
     "frcnn_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "frcnn_rpn_targets_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_rpn_targets": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
@@ -160,6 +161,15 @@ def stream_ptr(device: torch.device) -> int:
 def ptr_table(tensors: Sequence[torch.Tensor]):
     """Host array of device pointers (the `*_multi` entry points' pointer tables)."""
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def gather_copy_multi(pairs: Sequence[Tuple[int, int, int]], stream: int) -> None:
+    """One launch copying every ``(src_ptr, dst_ptr, nbytes)`` of ``pairs`` (at most 8; device -> device / pinned host)."""
+    n = len(pairs)
+    srcs = (ctypes.c_void_p * n)(*[p[0] for p in pairs])
+    dsts = (ctypes.c_void_p * n)(*[p[1] for p in pairs])
+    sizes = (ctypes.c_size_t * n)(*[p[2] for p in pairs])
+    check(lib().frcnn_gather_copy_multi(srcs, dsts, sizes, n, stream))
 
 
 def float4(values: Sequence[float]):

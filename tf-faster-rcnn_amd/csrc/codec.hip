@@ -85,6 +85,29 @@ __global__ __launch_bounds__(256) void gather_copy_kernel(const uint4 *__restric
   if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
+// Up to kGatherSegments (src, dst, bytes) copies in ONE launch: blockIdx.y selects the segment.
+static const int kGatherSegments = 8;
+struct GatherSegments {
+  const uint4 *src[kGatherSegments];
+  uint4 *dst[kGatherSegments];
+  long long n16[kGatherSegments];  // 16-byte units (sizes are multiples of 16)
+};
+
+__global__ __launch_bounds__(256) void gather_copy_multi_kernel(GatherSegments g) {
+  const uint4 *__restrict__ src = g.src[0];
+  uint4 *__restrict__ dst = g.dst[0];
+  long long n16 = g.n16[0];
+#pragma unroll
+  for (int i = 1; i < kGatherSegments; ++i) {  // block-uniform selects: no dynamic indexing of the kernel arguments
+    if ((int)blockIdx.y == i) {
+      src = g.src[i];
+      dst = g.dst[i];
+      n16 = g.n16[i];
+    }
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace frcnn
 
 using namespace frcnn;
@@ -171,6 +194,31 @@ int frcnn_gather_copy(const void *src, void *dst, size_t bytes, frcnn_stream_t s
                      reinterpret_cast<const unsigned char *>(src) + n16 * 16, reinterpret_cast<unsigned char *>(dst) + n16 * 16,
                      tail);
   return check_launch("gather_copy");
+}
+
+int frcnn_gather_copy_multi(const void *const *srcs, void *const *dsts, const size_t *bytes, int n, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(srcs && dsts && bytes, "gather_copy_multi: null table");
+  FRCNN_REQUIRE(n >= 0 && n <= kGatherSegments, "gather_copy_multi: 0..%d segments (got %d)", kGatherSegments, n);
+  GatherSegments g = {};
+  long long most = 0;
+  int used = 0;
+  for (int i = 0; i < n; ++i) {
+    if (bytes[i] == 0) continue;
+    FRCNN_REQUIRE(srcs[i] && dsts[i], "gather_copy_multi: null pointer in segment %d", i);
+    FRCNN_REQUIRE(aligned_to(srcs[i], 16) && aligned_to(dsts[i], 16) && bytes[i] % 16 == 0,
+                  "gather_copy_multi: segment %d must be 16-byte aligned and a multiple of 16 bytes", i);
+    FRCNN_REQUIRE(bytes[i] < ((size_t)1 << 40), "gather_copy_multi: segment %d too large", i);
+    g.src[used] = reinterpret_cast<const uint4 *>(srcs[i]);
+    g.dst[used] = reinterpret_cast<uint4 *>(dsts[i]);
+    g.n16[used] = (long long)(bytes[i] / 16);
+    most = g.n16[used] > most ? g.n16[used] : most;
+    ++used;
+  }
+  if (used == 0) return FRCNN_OK;
+  long long bx = (most + 255) / 256;
+  if (bx > 4096) bx = 4096;  // grid-stride beyond that
+  hipLaunchKernelGGL(gather_copy_multi_kernel, dim3((unsigned)bx, (unsigned)used), dim3(256), 0, (hipStream_t)stream, g);
+  return check_launch("gather_copy_multi");
 }
 
 }  // extern "C"

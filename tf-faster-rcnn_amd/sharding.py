@@ -155,6 +155,7 @@ class SharedHostGather:
         k = step % self.slots
         if self._staged[k] >= 0:
             self._publish(k)  # the step that used this staging slot `slots` steps ago: long complete in a running loop
+        pairs = []
         for name, (off, shape, dtype, row, loc) in self._layout.items():
             local = outputs[name]
             if local.numel() != n * (row // local.element_size()) or local.dtype != dtype or not local.is_contiguous():
@@ -165,11 +166,14 @@ class SharedHostGather:
                 start = k * self.slot_bytes + off + self.lo * row
                 self._host[start:start + n * row].copy_(local.reshape(-1).view(torch.uint8))
             else:
-                from . import _lib
-                if stream is None:
-                    stream = _lib.stream_ptr(self.device)
-                with _lib.on_device(self.device):
-                    _lib.check(_lib.lib().frcnn_gather_copy(local.data_ptr(), self._stage[k].data_ptr() + loc, n * row, stream))
+                pairs.append((local.data_ptr(), self._stage[k].data_ptr() + loc, n * row))
+        if pairs:
+            from . import _lib
+            if stream is None:
+                stream = _lib.stream_ptr(self.device)
+            with _lib.on_device(self.device):
+                for i in range(0, len(pairs), 8):  # one copy launch per 8 sections
+                    _lib.gather_copy_multi(pairs[i:i + 8], stream)
         if self.device is not None and n > 0:
             self._events[k].record(stream)
             self._staged[k] = step
