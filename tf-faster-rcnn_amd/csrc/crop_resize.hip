@@ -185,7 +185,7 @@ __device__ __forceinline__ int crop_slot_role(int slot, int start, int count, in
 __global__ __launch_bounds__(256) void crop_resize_slice_kernel(
     const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
     const int *__restrict__ box_ind, const int *__restrict__ order, int n, int boxes_per_image, int ch, int cw, float extrap,
-    float *__restrict__ out, int S, int SW, int pf_blocks, int pf_lead) {
+    float *__restrict__ out, int S, int SW, int pf_blocks, int pf_lead, int pf_linear) {
   __shared__ PixParam pp[256];
   const int tid = threadIdx.x;
   const int grp = blockIdx.x & 7;
@@ -210,13 +210,29 @@ __global__ __launch_bounds__(256) void crop_resize_slice_kernel(
       const int piece = -1 - role;
       const int img_i = pf_box / boxes_per_image;
       if (img_i >= B) return;
-      const char *src = reinterpret_cast<const char *>(image + (long long)img_i * H * W * C) + (size_t)c0 * 16;
-      const int total = H * W * sw;  // float4 of the slice
       f32x4 acc = (f32x4)(0.0f);
-      for (int e = piece * 256 + tid; e < total; e += pf_blocks * 256) {
-        const int px = e / sw, c = e - px * sw;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)px * ((size_t)C * 4) + (size_t)c * 16);
-        acc.x += v.x;  // (any use keeps the load; nothing is stored)
+      if (pf_linear) {
+        // the S XCDs of the lane group read one contiguous S-th of the image each (full lines, no address arithmetic): the
+        // whole image lands in the memory-side Infinity Cache, from where every XCD's taps are served
+        const long long image_bytes = (long long)H * W * C * 4;
+        const long long part = (image_bytes / S + 15) & ~15ll;
+        const long long lo = (long long)slice * part;
+        const long long hi = (lo + part < image_bytes) ? lo + part : image_bytes;
+        const char *src = reinterpret_cast<const char *>(image + (long long)img_i * H * W * C);
+#pragma unroll 8
+        for (long long o = lo + ((long long)piece * 256 + tid) * 16; o + 16 <= hi; o += (long long)pf_blocks * 256 * 16) {
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(src + o);
+          acc.x += v.x;
+        }
+      } else {
+        const char *src = reinterpret_cast<const char *>(image + (long long)img_i * H * W * C) + (size_t)c0 * 16;
+        const int total = H * W * sw;  // float4 of the slice
+#pragma unroll 8
+        for (int e = piece * 256 + tid; e < total; e += pf_blocks * 256) {
+          const int px = e / sw, c = e - px * sw;
+          const f32x4 v = *reinterpret_cast<const f32x4 *>(src + (size_t)px * ((size_t)C * 4) + (size_t)c * 16);
+          acc.x += v.x;  // (any use keeps the load; nothing is stored)
+        }
       }
       asm volatile("" ::"v"(acc));
       return;
@@ -343,6 +359,7 @@ void crop_resize_kernel(
       const long long image_bytes = (long long)H * W * C * 4;
       const char *src = reinterpret_cast<const char *>(image) + (long long)img_i * image_bytes;
       f32x4 acc = (f32x4)(0.0f);
+#pragma unroll 8
       for (long long o = ((long long)piece * 256 + tid) * 16; o + 16 <= image_bytes; o += (long long)gr.pf_blocks * 256 * 16) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + o);
         acc.x += v.x;  // (any use keeps the load; nothing is stored)
@@ -485,7 +502,7 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   if (use_slice) {
     const int CV = C / 4, SW = (CV + 7) / 8;
     hipLaunchKernelGGL(crop_resize_slice_kernel, dim3((unsigned)n * 8u), block, 0, (hipStream_t)stream, image, B, H, W, C,
-                       boxes, box_ind, (const int *)nullptr, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out, 8, SW, 0, 0);
+                       boxes, box_ind, (const int *)nullptr, n, boxes_per_image, crop_h, crop_w, extrapolation_value, out, 8, SW, 0, 0, 0);
     return check_launch("crop_and_resize");
   }
   // FRCNN_CROP_ROWS=0|1 forces the (box) / (box, output row) decomposition (diagnostic).
@@ -528,14 +545,15 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
   FRCNN_REQUIRE((long long)B * R < (1ll << 28), "roi_pooling: too many RoIs");
   const int n = B * R;
   const long long image_bytes = (long long)H * W * C * 4;
-  // Feature maps beyond an XCD's 4 MiB L2 (config 5: 9.1 MB) take the channel-slice kernel with the channels cut over all
-  // 8 XCDs.  Measured at config 5 (16 images, cold inputs, us per launch; profiles/r02_*cfg5*): S = 8 217-230, S = 4 222,
-  // S = 2 214, box kernel 240; sweeping every image's RoIs top to bottom (FRCNN_CROP_SORT=1, roi_order_kernel) is SLOWER
-  // (S = 8 279, S = 4 253-266, S = 2 246) although its HBM traffic is ideal (FETCH 160 MB for 146 MB of feature maps,
-  // WRITE 537 MB); warm-up workgroups (FRCNN_CROP_PREFETCH) do not help the slice kernel either (S = 8 273, S = 4 221).
-  // FRCNN_CROP_SPLIT = S forces S (0 = never this schedule).
+  // Feature maps beyond an XCD's 4 MiB L2 (config 5: 9.1 MB) take the channel-slice kernel: channels cut over S XCDs, S the
+  // smallest of 2 / 4 / 8 that brings an XCD's share of an image under 2.5 MB, with warm-up workgroups one image ahead.
+  // Measured at config 5 (16 images, COLD inputs, us per launch; profiles/r02_*cfg5*): S = 4 with warm-up 190-194,
+  // S = 8 without 217-230 (round 1's schedule), S = 4 without 222, S = 2 214, box kernel 240; warm inputs: S = 4 151
+  // without warm-up, 172-175 with.  Sweeping every image's RoIs top to bottom (FRCNN_CROP_SORT=1, roi_order_kernel) is
+  // SLOWER (S = 8 279, S = 4 253-266, S = 2 246) although its HBM traffic is ideal (FETCH 160 MB for 146 MB of feature
+  // maps, WRITE 537 MB).  FRCNN_CROP_SPLIT = S forces S (0 = never this schedule).
   int S = knob(kKnobCropSplit, -1);
-  if (S < 0) S = image_bytes <= 4ll * 1024 * 1024 ? 0 : 8;
+  if (S < 0) S = image_bytes <= 4ll * 1024 * 1024 ? 0 : (image_bytes <= 5ll * 1024 * 1024 ? 2 : (image_bytes <= 10ll * 1024 * 1024 ? 4 : 8));
   const bool shape_ok = H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
                         aligned_to(out, 16) && aligned_to(rois, 16) && (long long)crop_h * crop_w * C * 4 < (1ll << 32) &&
                         image_bytes < (1ll << 32) && (long long)crop_h * crop_w < (1ll << 24);
@@ -553,8 +571,13 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
     const int CV = C / 4, SW = (CV + S - 1) / S, nlg = 8 / S;
     long long slots = (n + nlg - 1) / nlg;
     // warm-up workgroups (unsorted sweep only: a sorted sweep has no "first box of the next image" in slot order that
-    // the image-by-image warm-up could lead): FRCNN_CROP_PREFETCH as for the box kernel; off by default (no gain measured)
-    int pf = order ? 0 : knob(kKnobCropPrefetch, 0), lead = 128;
+    // the image-by-image warm-up could lead): FRCNN_CROP_PREFETCH as for the box kernel; by default 32 workgroups per (XCD,
+    // image), one image (R boxes) ahead: 16 / 32 / 96 workgroups -> 194 / 190 / 190 us, lead 128 / 200 / 300 -> 221 / 199 / 193
+    int pf = order ? 0 : knob(kKnobCropPrefetch, 32), lead = R < 128 ? 128 : (R > 512 ? 512 : R), linear = 0;
+    if (pf >= 100000000) {  // diagnostic: + 100000000 = linear (Infinity Cache) warm-up instead of the XCD's own slice
+      linear = 1;
+      pf -= 100000000;
+    }
     if (pf >= 10000) {
       lead = pf / 10000;
       pf %= 10000;
@@ -563,7 +586,7 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
     if (pf > 0) slots += ((slots + R - 2) / R + 1) * pf;
     FRCNN_REQUIRE(slots * 8 < (1ll << 31), "roi_pooling: too many workgroups");
     hipLaunchKernelGGL(crop_resize_slice_kernel, dim3((unsigned)slots * 8u), dim3(256), 0, (hipStream_t)stream, feature_map, B, H,
-                       W, C, rois, (const int *)nullptr, order, n, R, crop_h, crop_w, 0.0f, out, S, SW, pf, lead);
+                       W, C, rois, (const int *)nullptr, order, n, R, crop_h, crop_w, 0.0f, out, S, SW, pf, lead, linear);
     return check_launch("roi_pooling");
   }
   return frcnn_crop_and_resize(feature_map, B, H, W, C, rois, nullptr, n, R, crop_h, crop_w, 0.0f, out, stream);
