@@ -126,46 +126,139 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
       exhausted = true;
     }
     // ---- 2. compact the slice (in2 and not in1) in index order --------------------------------------
-    int e1 = 0, e2 = 0;
-    for (int i = i0; i < i1; ++i) {
-      uint32_t k;
-      keyf(i, k);
-      e1 += (k == T1);
-      e2 += (k == T2);
-    }
-    int tot;
-    const int base1 = block_excl_scan<NT>(e1, wsum, tot);
-    const int base2 = block_excl_scan<NT>(e2, wsum, tot);
-    int cnt = 0;
-    {
-      int r1 = base1, r2 = base2;
-      for (int i = i0; i < i1; ++i) {
-        uint32_t k;
-        keyf(i, k);
-        const bool in1 = (k < T1) || (k == T1 && r1 < eq1);
-        const bool in2 = (k < T2) || (k == T2 && r2 < eq2);
-        r1 += (k == T1);
-        r2 += (k == T2);
-        cnt += (in2 && !in1);
-      }
-    }
     int V;
-    int pos = block_excl_scan<NT>(cnt, wsum, V);
-    {
-      int r1 = base1, r2 = base2;
+    if (cache_keys) {
+      // keys in LDS: every thread owns a contiguous run of elements
+      int e1 = 0, e2 = 0;
       for (int i = i0; i < i1; ++i) {
         uint32_t k;
         keyf(i, k);
-        const bool in1 = (k < T1) || (k == T1 && r1 < eq1);
-        const bool in2 = (k < T2) || (k == T2 && r2 < eq2);
-        r1 += (k == T1);
-        r2 += (k == T2);
-        if (in2 && !in1 && pos < S) {
-          keys[pos] = k;
-          orig[pos] = (uint32_t)i;
-          permA[pos] = (uint16_t)pos;
-          ++pos;
+        e1 += (k == T1);
+        e2 += (k == T2);
+      }
+      int tot;
+      const int base1 = block_excl_scan<NT>(e1, wsum, tot);
+      const int base2 = block_excl_scan<NT>(e2, wsum, tot);
+      int cnt = 0;
+      {
+        int r1 = base1, r2 = base2;
+        for (int i = i0; i < i1; ++i) {
+          uint32_t k;
+          keyf(i, k);
+          const bool in1 = (k < T1) || (k == T1 && r1 < eq1);
+          const bool in2 = (k < T2) || (k == T2 && r2 < eq2);
+          r1 += (k == T1);
+          r2 += (k == T2);
+          cnt += (in2 && !in1);
         }
+      }
+      int pos = block_excl_scan<NT>(cnt, wsum, V);
+      {
+        int r1 = base1, r2 = base2;
+        for (int i = i0; i < i1; ++i) {
+          uint32_t k;
+          keyf(i, k);
+          const bool in1 = (k < T1) || (k == T1 && r1 < eq1);
+          const bool in2 = (k < T2) || (k == T2 && r2 < eq2);
+          r1 += (k == T1);
+          r2 += (k == T2);
+          if (in2 && !in1 && pos < S) {
+            keys[pos] = k;
+            orig[pos] = (uint32_t)i;
+            permA[pos] = (uint16_t)pos;
+            ++pos;
+          }
+        }
+      }
+    } else {
+      // keys in global memory (N beyond the LDS cache, e.g. 35721 anchors at config 5): a contiguous run per THREAD would
+      // read them with a stride of N/NT elements between lanes (48 us at config 5).  Here a WAVE owns a contiguous chunk and
+      // walks it 64 consecutive elements at a time (one coalesced 256-byte read per round); index order inside a round
+      // comes from ballots, across rounds from running counts, across waves from a 16-entry scan.
+      const int lane = tid & 63, w = tid >> 6;
+      const int CW = ((N + kNW - 1) / kNW + 63) & ~63;  // chunk per wave, a multiple of 64
+      const int c0 = w * CW;
+      const int rounds = CW >> 6;
+      const unsigned long long lt = lanemask_lt();
+      // one sweep over the wave's chunk: eight rounds' keys are loaded before the first is used (the ballots make the
+      // loop body convergent, which rules out the compiler's own unrolling of a run-time trip count)
+      auto sweep = [&](auto body) {
+        for (int r = 0; r < rounds; r += 8) {
+          uint32_t kk[8];
+          bool lv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = c0 + ((r + u) << 6) + lane;
+            lv[u] = (r + u < rounds) && (i < N);
+            kk[u] = 0xFFFFFFFFu;
+            if (lv[u]) keyf(i, kk[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) body(c0 + ((r + u) << 6) + lane, kk[u], lv[u]);
+        }
+      };
+      // sweep 1: elements equal to T1 / T2 per wave
+      int n1 = 0, n2 = 0;
+      sweep([&](int, uint32_t k, bool live) {
+        n1 += __popcll(ballot64(live && k == T1));
+        n2 += __popcll(ballot64(live && k == T2));
+      });
+      __syncthreads();  // wsum may still be read by the selection
+      if (lane == 0) {
+        wsum[w] = n1;
+        wsum[kNW + w] = n2;
+      }
+      __syncthreads();
+      int base1 = 0, base2 = 0;
+#pragma unroll
+      for (int ww = 0; ww < kNW; ++ww) {
+        base1 += (ww < w) ? wsum[ww] : 0;
+        base2 += (ww < w) ? wsum[kNW + ww] : 0;
+      }
+      // sweep 2: selected elements per wave
+      int nsel = 0;
+      {
+        int r1 = base1, r2 = base2;
+        sweep([&](int, uint32_t k, bool live) {
+          const unsigned long long b1 = ballot64(live && k == T1), b2 = ballot64(live && k == T2);
+          const int q1 = r1 + __popcll(b1 & lt), q2 = r2 + __popcll(b2 & lt);
+          const bool in1 = live && ((k < T1) || (k == T1 && q1 < eq1));
+          const bool in2 = live && ((k < T2) || (k == T2 && q2 < eq2));
+          nsel += __popcll(ballot64(in2 && !in1));
+          r1 += __popcll(b1);
+          r2 += __popcll(b2);
+        });
+      }
+      __syncthreads();
+      if (lane == 0) wsum[w] = nsel;
+      __syncthreads();
+      int pos = 0;
+      V = 0;
+#pragma unroll
+      for (int ww = 0; ww < kNW; ++ww) {
+        pos += (ww < w) ? wsum[ww] : 0;
+        V += wsum[ww];
+      }
+      // sweep 3: place
+      {
+        int r1 = base1, r2 = base2;
+        sweep([&](int i, uint32_t k, bool live) {
+          const unsigned long long b1 = ballot64(live && k == T1), b2 = ballot64(live && k == T2);
+          const int q1 = r1 + __popcll(b1 & lt), q2 = r2 + __popcll(b2 & lt);
+          const bool in1 = live && ((k < T1) || (k == T1 && q1 < eq1));
+          const bool in2 = live && ((k < T2) || (k == T2 && q2 < eq2));
+          const bool sel = in2 && !in1;
+          const unsigned long long bs = ballot64(sel);
+          const int at = pos + __popcll(bs & lt);
+          if (sel && at < S) {
+            keys[at] = k;
+            orig[at] = (uint32_t)i;
+            permA[at] = (uint16_t)at;
+          }
+          pos += __popcll(bs);
+          r1 += __popcll(b1);
+          r2 += __popcll(b2);
+        });
       }
     }
     FRCNN_STAMP(3);

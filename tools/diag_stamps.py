@@ -18,9 +18,11 @@ import tf_faster_rcnn_amd as pkg
 lib = pkg._lib.lib()
 lib.frcnn_debug_stamps.restype = ctypes.c_int
 lib.frcnn_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+# optional: G K R on the command line (default BASELINE config 2: 32 6000 300; config 5: 63 12000 300)
+G_, K_, R_ = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 6000, 300)
+hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G_, pre_nms_topn=K_, test_nms_topn=R_)
 anchors = pkg.bbox_utils.generate_anchors(hp)
-d, s = synth.rpn_outputs(0, 16, 32)
+d, s = synth.rpn_outputs(0, 16, G_)
 d, s = torch.as_tensor(d).cuda(), torch.as_tensor(s).cuda()
 layer = pkg.faster_rcnn.RoIBBox(anchors, "inference", hp)
 buf = np.zeros(256, dtype=np.int64)
@@ -36,6 +38,9 @@ for it in range(3):
         for i in range(n):
             print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
 
+
+if len(sys.argv) >= 4:
+    sys.exit(0)
 
 # ---- the same kernel while the crop kernel fills the chip on another stream (stage pipeline conditions) ----------
 # Workgroup 0's phases run at their stand-alone speed (82.6 us against 80.0): what the pipeline loses is RESIDENCY, not
