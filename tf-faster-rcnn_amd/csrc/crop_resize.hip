@@ -607,8 +607,12 @@ extern "C" int frcnn_crop_and_resize_multi(const float *const *images, const flo
   }
   if (!one_launch) {  // shapes the grouped launch is not built for: one launch per triple, same results
     for (int g = 0; g < groups; ++g) {
-      const int rc = frcnn_crop_and_resize(images[g], B, H, W, C, boxes[g], nullptr, n, boxes_per_image, crop_h, crop_w,
-                                           extrapolation_value, outs[g], stream);
+      // (the RoIPooling layout with extrapolation 0 goes through the layer-level entry point: it picks the schedule for
+      // feature maps beyond L2)
+      const int rc = (extrapolation_value == 0.0f && n == B * boxes_per_image && B > 0)
+                         ? frcnn_roi_pooling(images[g], B, H, W, C, boxes[g], boxes_per_image, crop_h, crop_w, outs[g], nullptr, 0, stream)
+                         : frcnn_crop_and_resize(images[g], B, H, W, C, boxes[g], nullptr, n, boxes_per_image, crop_h, crop_w,
+                                                 extrapolation_value, outs[g], stream);
       if (rc) return rc;
     }
     return FRCNN_OK;
