@@ -39,6 +39,8 @@ def test_fuzz_roi_bbox_all_schedules(pkg, knobs):
         if schedule == "unfused":
             knobs.setenv("FRCNN_ROI_BBOX_UNFUSED", "1")
         knobs.setenv("FRCNN_PROPOSAL_THREADS", "256" if (case // 3) % 2 else "1024")  # block size of the fused kernel
+        knobs.setenv("FRCNN_PROPOSAL_EXACT_SLICES", "1" if (case // 6) % 2 else "0")   # exact-rank slices / sampled cuts
+        knobs.setenv("FRCNN_PROPOSAL_CHUNK", ("64", "128", "256")[(case // 12) % 3])    # NMS chunk width
         hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
         hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
         anchors = oracle.generate_anchors(hp)
@@ -48,6 +50,40 @@ def test_fuzz_roi_bbox_all_schedules(pkg, knobs):
         got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
         want = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, thr)
         assert_bits(got, want, f"RoIBBox fuzz case {case}: {schedule} B={B} G={G} K={K} R={R} thr={thr}")
+
+
+def test_roi_bbox_fast_slices_score_distributions(pkg, knobs):
+    """The fused kernel cuts its slices at a sampled key boundary and bucket-sorts them; score distributions that
+    stress the cut (heavy 16-bit prefix bins), the buckets (clusters, ties) and the fall-back to the exact selection."""
+    rng = np.random.default_rng(31)
+    G, K, R = 20, 3000, 300
+    N = G * G * 9
+    dists = {
+        "uniform": lambda: rng.random((2, N)),
+        "sigmoid_saturated": lambda: 1.0 / (1.0 + np.exp(-8.0 * rng.normal(0, 1, (2, N)))),
+        "constant": lambda: np.full((2, N), 0.25),
+        "two_values": lambda: rng.choice([0.125, 0.75], (2, N)),
+        "few_values": lambda: rng.choice(rng.random(40), (2, N)),
+        "tight_cluster": lambda: 0.5 + 1e-6 * rng.random((2, N)),
+        "tiny": lambda: 1e-30 * rng.random((2, N)),
+        "signed_wide": lambda: rng.normal(0, 1e4, (2, N)),
+        "mixed_ties": lambda: np.where(rng.random((2, N)) < 0.5, 0.9, rng.random((2, N))),
+        "exponential": lambda: np.exp(-30.0 * rng.random((2, N))),
+    }
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R)
+    anchors = oracle.generate_anchors(hp)
+    layer = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)
+    for name, draw in dists.items():
+        for scale in (1.0, 0.05):  # little suppression (one slice) / heavy suppression (several slices)
+            deltas, _ = synth.rpn_outputs(700, 2, G)
+            deltas = (deltas * scale).astype(np.float32)
+            scores = draw().astype(np.float32).reshape(2, G, G, 9)
+            want = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, 0.7)
+            for exact in ("0", "1"):
+                knobs.setenv("FRCNN_PROPOSAL_EXACT_SLICES", exact)
+                got = layer([dev(deltas), dev(scores)])
+                assert_bits(got, want, f"RoIBBox scores={name} delta_scale={scale} exact_slices={exact}")
 
 
 def test_roi_bbox_minus_inf_scores_all_schedules(pkg, knobs):

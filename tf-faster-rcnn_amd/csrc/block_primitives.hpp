@@ -139,6 +139,112 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
   __syncthreads();
 }
 
+// The two upper passes of radix_select only: P = the smallest 16-bit prefix such that at least `need` valid keys have
+// (key >> 16) <= P, and cnt_le = how many valid keys that is (>= need; the surplus is what the prefix's bin holds beyond
+// the rank asked for).  all = true when fewer than `need` valid keys exist (then P = 0xFFFF and cnt_le = their number).
+// low_byte = the smallest top byte any valid key has (0 when there is none): low_byte << 24 bounds every key from below.
+// misc: >= 5 ints.
+// Half the passes of the exact selection, for callers that may cut their slice at any key boundary near a rank.
+template <int NT = kNT, class KeyF>
+__device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint32_t *hist, int *misc, uint32_t &P,
+                                                int &cnt_le, bool &all, uint32_t &low_byte) {
+  constexpr int kNT = NT, kNW = NT / 64;
+  static_assert(NT >= 256 && NT % 64 == 0, "prefix16_select: the 256 bins are summed by the first 256 threads");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  __syncthreads();
+  if (tid == 0) misc[2] = 0;
+  uint32_t prefix = 0;
+  int below = 0;  // valid keys whose prefix is smaller than the bin chosen so far
+  all = false;
+  cnt_le = 0;
+  for (int pass = 1; pass >= 0; --pass) {
+    const int shift = 16 + pass * 8;
+    for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
+    __syncthreads();
+    uint32_t *myhist = hist + w * 256;
+    if (pass == 1) {
+      const int n_up = (n + kNT - 1) / kNT * kNT;
+      for (int i = tid; i < n_up; i += kNT) {
+        uint32_t k = 0;
+        const bool v = (i < n) && keyf(i, k);
+        hist_add(myhist, (k >> shift) & 255u, v);
+      }
+    } else {
+      for (int i = tid; i < n; i += kNT) {
+        uint32_t k = 0;
+        if (keyf(i, k) && (k >> 24) == prefix) atomicAdd(&myhist[(k >> shift) & 255u], 1u);
+      }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      uint32_t sum = 0;
+#pragma unroll
+      for (int ww = 0; ww < kNW; ++ww) sum += hist[ww * 256 + tid];
+      hist[tid] = sum;
+    }
+    __syncthreads();
+    if (w == 0) {
+      const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+      const uint32_t s4 = h0 + h1 + h2 + h3;
+      uint32_t inc = s4;
+      inc = wave_incl_scan(inc);
+      const uint32_t exc = inc - s4;
+      const bool here = (exc < (uint32_t)need) && (inc >= (uint32_t)need);
+      const unsigned long long bal = ballot64(here);
+      if (pass == 1) {
+        const unsigned long long occ = ballot64(s4 != 0u);
+        if (occ == 0ull) {
+          if (lane == 0) misc[4] = 0;
+        } else if (lane == (int)__builtin_ctzll(occ)) {
+          misc[4] = 4 * lane + (h0 ? 0 : h1 ? 1 : h2 ? 2 : 3);
+        }
+      }
+      if (bal == 0ull) {
+        if (lane == 63) {
+          misc[2] = 1;
+          misc[3] = (int)inc;  // every valid key
+        }
+      } else if (here) {
+        uint32_t cum = exc, hd = h0;
+        int d = 4 * lane;
+        if (cum + h0 < (uint32_t)need) {
+          cum += h0;
+          hd = h1;
+          ++d;
+          if (cum + h1 < (uint32_t)need) {
+            cum += h1;
+            hd = h2;
+            ++d;
+            if (cum + h2 < (uint32_t)need) {
+              cum += h2;
+              hd = h3;
+              ++d;
+            }
+          }
+        }
+        misc[0] = (int)((prefix << 8) | (uint32_t)d);
+        misc[1] = (int)cum;         // keys of this pass below the chosen bin
+        misc[3] = (int)(cum + hd);  // ... and up to its end
+      }
+    }
+    __syncthreads();
+    if (misc[2]) {  // only possible in the first pass (the second looks inside a bin that holds the rank)
+      all = true;
+      prefix = 0xFFFFu;
+      cnt_le = below + misc[3];
+      break;
+    }
+    prefix = (uint32_t)misc[0];
+    cnt_le = below + misc[3];
+    below += misc[1];
+    need -= misc[1];
+    __syncthreads();  // misc is rewritten by the next pass
+  }
+  P = prefix;
+  low_byte = (uint32_t)misc[4];
+  __syncthreads();
+}
+
 // Stable least-significant-digit radix sort of V slot numbers: `npass` passes of 8 bits, digit(slot, pass)
 // gives the pass's digit of a slot (pass 0 = least significant).  perm[0..V) holds the initial order
 // (normally 0..V-1); perm[stride..stride+V) is the ping-pong half.  Returns the offset (0 or stride) of the

@@ -44,6 +44,7 @@ enum Knob {
   kKnobCropSplit,        // FRCNN_CROP_SPLIT            channel slices of frcnn_roi_pooling's large-image schedule (0 | 2 | 4 | 8)
   kKnobCropSort,         // FRCNN_CROP_SORT             0 = keep the RoIs in their given order there
   kKnobIouReduceSplit,   // FRCNN_IOU_REDUCE_SPLIT      0|1: the 64 boxes x 4 gt quarters form of the fused IoU reductions
+  kKnobProposalExactSlices,  // FRCNN_PROPOSAL_EXACT_SLICES 1: the fused RoIBBox kernel cuts its slices by exact rank only
   kKnobCount
 };
 bool knob_set(Knob k);

@@ -63,6 +63,18 @@ __device__ __forceinline__ PBox load_pbox(const float4 *box, const float2 *af, i
   return p;
 }
 
+__device__ __forceinline__ PBox load_pbox(const float4 *box, const float *area, const int *flag, int i) {
+  const float4 b = box[i];
+  PBox p;
+  p.ymin = b.x;
+  p.xmin = b.y;
+  p.ymax = b.z;
+  p.xmax = b.w;
+  p.area = area[i];
+  p.flag = flag[i];
+  return p;
+}
+
 __device__ __forceinline__ NBox to_nbox(const PBox &p) {
   NBox n;
   n.ymin = p.ymin;
@@ -101,23 +113,64 @@ __device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, co
   return yes & area_ok;
 }
 
+// The band filter for TWO row boxes (a, b) against one box `me`, all three REGULAR (finite, area in [1e-30, 5e29]: no
+// flags to look at), as packed fp32: the subtractions, products and scalings of the two tests share v_pk_add_f32 /
+// v_pk_mul_f32 (13 VALU instructions per pair instead of 19; only max / min have no packed form).  Same operations, same
+// roundings as nms_iou_gt_fast.  a_area2 = (area a, area b).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void nms_iou_gt_fast2(const float4 &me, float me_area, const float4 &a, const float4 &b, v2f ab_area,
+                                                 float thr, bool &yes_a, bool &yes_b, bool &irr) {
+  v2f mny, mxy, mnx, mxx;
+  mny.x = hw_min(me.z, a.z);
+  mny.y = hw_min(me.z, b.z);
+  mxy.x = hw_max(me.x, a.x);
+  mxy.y = hw_max(me.x, b.x);
+  mnx.x = hw_min(me.w, a.w);
+  mnx.y = hw_min(me.w, b.w);
+  mxx.x = hw_max(me.y, a.y);
+  mxx.y = hw_max(me.y, b.y);
+  v2f ih = mny - mxy;
+  v2f iw = mnx - mxx;
+  ih.x = hw_max(ih.x, 0.0f);
+  ih.y = hw_max(ih.y, 0.0f);
+  iw.x = hw_max(iw.x, 0.0f);
+  iw.y = hw_max(iw.y, 0.0f);
+  const v2f inter = ih * iw;
+  const v2f me2 = {me_area, me_area};
+  v2f uni = me2 + ab_area;
+  uni = uni - inter;
+  const v2f thr2 = {thr, thr};
+  const v2f tt = thr2 * uni;
+  const v2f c_hi = {1.000000476837158203125f, 1.000000476837158203125f};
+  const v2f c_lo = {0.999999523162841796875f, 0.999999523162841796875f};
+  const v2f hi = tt * c_hi;
+  const v2f lo = tt * c_lo;
+  yes_a = inter.x > hi.x;
+  yes_b = inter.y > hi.y;
+  const bool no_a = inter.x < lo.x, no_b = inter.y < lo.y;
+  irr = irr | !(yes_a | no_a) | !(yes_b | no_b);
+}
+
 // LDS layout for chunks of CH candidates (CH = 64 * G).
 template <int CH>
 struct NmsLds {
   unsigned long long *mask;  // [CH * G] intra-chunk column words, mask[column * G + row group]
-  unsigned long long *dead;  // [4]
+  unsigned long long *dead;  // [4] per 64-candidate group: candidates removed so far
+  unsigned long long *reg;   // [4] per group: candidates whose flags are kFlagArea | kFlagRegular
   float4 *c_box;             // [CH] chunk boxes (corner-normalised)
-  float2 *c_af;              // [CH] (area, flags)
+  float *c_area;             // [CH]
+  int *c_flag;               // [CH]
   int *c_idx;                // [CH] element index of each chunk candidate
-  int *s_nk;                 // [4]
-  float4 *k_box;             // [Rc] kept boxes
-  float2 *k_af;              // [Rc]
+  int *s_nk;                 // [4]: [0] the kept count handed back, [1] every kept box so far is regular
+  float4 *k_box;             // [Rc] kept boxes; the entries from the kept count up to the next multiple of 4 are null boxes
+  float *k_area;             // [Rc]
+  int *k_flag;               // [Rc]
   int *k_idx;                // [Rc]
 };
 
 template <int CH>
 __host__ __device__ static inline size_t nms_lds_bytes(int Rc) {
-  return (size_t)CH * (CH / 64) * 8 + 4 * 8 + (size_t)CH * 28 + 4 * 4 + (size_t)Rc * 28;
+  return (size_t)CH * (CH / 64) * 8 + 8 * 8 + (size_t)CH * 28 + 4 * 4 + (size_t)Rc * 28;
 }
 
 // Rc must be a multiple of 4 (keeps every sub-array 16-byte aligned).
@@ -126,11 +179,14 @@ __device__ __forceinline__ NmsLds<CH> carve_nms_lds(unsigned char *smem, int Rc)
   NmsLds<CH> L;
   L.mask = reinterpret_cast<unsigned long long *>(smem);
   L.dead = L.mask + CH * (CH / 64);
-  L.c_box = reinterpret_cast<float4 *>(L.dead + 4);
+  L.reg = L.dead + 4;
+  L.c_box = reinterpret_cast<float4 *>(L.reg + 4);
   L.k_box = L.c_box + CH;
-  L.c_af = reinterpret_cast<float2 *>(L.k_box + Rc);
-  L.k_af = L.c_af + CH;
-  L.c_idx = reinterpret_cast<int *>(L.k_af + Rc);
+  L.c_area = reinterpret_cast<float *>(L.k_box + Rc);
+  L.k_area = L.c_area + CH;  // (16-byte aligned: CH and Rc are multiples of 4)
+  L.c_flag = reinterpret_cast<int *>(L.k_area + Rc);
+  L.k_flag = L.c_flag + CH;
+  L.c_idx = L.k_flag + Rc;
   L.k_idx = L.c_idx + CH;
   L.s_nk = L.k_idx + Rc;
   return L;
@@ -149,24 +205,20 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// One chunk of nc (<= CH) candidates, in priority order.  cand(j, box, ei, bad) fills candidate j's box
-// (original corner order), element index and "fails the score threshold" flag (called by threads j < nc).
-// nk = boxes kept so far; returns the new count (<= R).  Must be called by all NT threads of the block.
+// One chunk of nc (<= CH) candidates, in priority order, whose packed boxes (L.c_box, L.c_af), element indices (L.c_idx)
+// and initial dead words (L.dead[g]: candidates that fail the score threshold) are already in LDS -- written by this
+// workgroup, but not necessarily published yet: the function starts with a barrier.  L.c_* may point anywhere in LDS (a
+// slice decoded ahead of time); entries [nc, CH) are read but never influence a result.  nk = boxes kept so far; returns
+// the new count (<= R).  Must be called by all NT threads of the block.
+template <int NT, int CH>
+__device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr);
+
+// The same with the chunk loaded here: cand(j, box, ei, bad) fills candidate j's box (original corner order), element
+// index and "fails the score threshold" flag (called by threads j < nc).
 template <int NT, int CH, class CandF>
 __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr, CandF cand) {
-  static_assert(CH == 64 || CH == 128 || CH == 256, "chunk must be 1, 2 or 4 waves wide");
   static_assert(NT >= CH && NT % CH == 0, "block must cover the chunk");
-  constexpr int G = CH / 64;
-  constexpr int NWV = NT / 64;
-  constexpr int NSL = NT / CH;                  // slices of the kept list handled in parallel
-  constexpr int TILES = G * (G + 1) / 2;        // upper-triangular 64x64 tiles
-  // row splits per tile: the largest power of two (<= 16) that keeps the work items within 4 per wave
-  constexpr int SPLIT = (TILES * 16 <= 4 * NWV) ? 16 : (TILES * 8 <= 4 * NWV) ? 8 : (TILES * 4 <= 4 * NWV) ? 4
-                        : (TILES * 2 <= 4 * NWV) ? 2 : 1;
-  constexpr int ROWS = 64 / SPLIT;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-  // ---- load the chunk --------------------------------------------------------------------------
   if (tid < CH) {
     NBox nb;
     nb.ymin = nb.xmin = nb.ymax = nb.xmax = nb.area = 0.0f;
@@ -179,11 +231,32 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       fl = box_flags(box, nb);
     }
     L.c_box[tid] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
-    L.c_af[tid] = make_float2(nb.area, __int_as_float(fl));
+    L.c_area[tid] = nb.area;
+    L.c_flag[tid] = fl;
     L.c_idx[tid] = ei;
     const unsigned long long badw = ballot64(bad);  // candidates that fail the score threshold start dead
-    if (lane == 0) L.dead[w] = badw;
+    const unsigned long long regw = ballot64(fl == (kFlagArea | kFlagRegular));
+    if (lane == 0) {
+      L.dead[w] = badw;
+      L.reg[w] = regw;
+    }
   }
+  return nms_chunk_resolve<NT, CH>(L, nc, nk, R, thr);
+}
+
+template <int NT, int CH>
+__device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr) {
+  static_assert(CH == 64 || CH == 128 || CH == 256, "chunk must be 1, 2 or 4 waves wide");
+  static_assert(NT >= CH && NT % CH == 0, "block must cover the chunk");
+  constexpr int G = CH / 64;
+  constexpr int NWV = NT / 64;
+  constexpr int NSL = NT / CH;                  // slices of the kept list handled in parallel
+  constexpr int TILES = G * (G + 1) / 2;        // upper-triangular 64x64 tiles
+  // row splits per tile: the largest power of two (<= 16) that keeps the work items within 4 per wave
+  constexpr int SPLIT = (TILES * 16 <= 4 * NWV) ? 16 : (TILES * 8 <= 4 * NWV) ? 8 : (TILES * 4 <= 4 * NWV) ? 4
+                        : (TILES * 2 <= 4 * NWV) ? 2 : 1;
+  constexpr int ROWS = 64 / SPLIT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < CH * G; i += NT) L.mask[i] = 0ull;  // column words, OR-ed together in phase b
   __syncthreads();
   FRCNN_STAMP(10);
@@ -193,15 +266,51 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
     const int j = tid & (CH - 1);
     const int slice = tid / CH;
     if ((j & ~63) < nc) {  // wave-uniform: this wave's 64 candidates exist
-      const PBox me = load_pbox(L.c_box, L.c_af, j);
+      const PBox me = load_pbox(L.c_box, L.c_area, L.c_flag, j);
       bool d = false;
+      const unsigned long long valid_w = (nc - (j & ~63) >= 64) ? ~0ull : ((1ull << (nc - (j & ~63))) - 1ull);
+      const bool all_regular = L.s_nk[1] != 0 && (uniform64(~L.reg[j >> 6]) & valid_w) == 0ull && !thr.slow_only;
+      if (all_regular) {
+        // every kept box and every candidate of this wave is regular: packed band filter, four consecutive kept boxes per
+        // step (the kept list is padded with null boxes up to a multiple of 4; a null box suppresses nobody)
+        const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+        const int ngroups = (nk + 3) >> 2;
+        for (int g4 = slice; g4 < ngroups; g4 += NSL) {
+          const float4 *kb = L.k_box + 4 * g4;
+          const float4 b0 = kb[0], b1 = kb[1], b2 = kb[2], b3 = kb[3];
+          const float4 ar = *reinterpret_cast<const float4 *>(L.k_area + 4 * g4);
+          const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
+          bool y0, y1, y2, y3, irr = false;
+          nms_iou_gt_fast2(meb, me.area, b0, b1, a01, thr.thr, y0, y1, irr);
+          nms_iou_gt_fast2(meb, me.area, b2, b3, a23, thr.thr, y2, y3, irr);
+          bool dd = y0 | y1 | y2 | y3;
+          if (__builtin_expect(ballot64(irr && j < nc) != 0ull, 0)) {  // inside the band: the reference formulation
+            const NBox men = to_nbox(me);
+            const float4 bb[4] = {b0, b1, b2, b3};
+            const float aa[4] = {ar.x, ar.y, ar.z, ar.w};
+            dd = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              NBox kn;
+              kn.ymin = bb[u].x;
+              kn.xmin = bb[u].y;
+              kn.ymax = bb[u].z;
+              kn.xmax = bb[u].w;
+              kn.area = aa[u];
+              dd = dd | nms_iou_gt(men, kn, thr.thr);
+            }
+          }
+          d = d | dd;
+          if (ballot64(!(d || (j >= nc))) == 0ull) break;
+        }
+      } else
       for (int k0 = slice; k0 < nk; k0 += 4 * NSL) {
         PBox kb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           int k = k0 + u * NSL;
           k = k < nk ? k : nk - 1;  // clamp: re-testing a kept box is harmless
-          kb[u] = load_pbox(L.k_box, L.k_af, k);
+          kb[u] = load_pbox(L.k_box, L.k_area, L.k_flag, k);
         }
         bool irr = false, dd = false;
 #pragma unroll
@@ -240,8 +349,10 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
     const int cg = rg + rem;
     if (rg * 64 >= nc || cg * 64 >= nc) continue;  // wave-uniform
     const int jcol = cg * 64 + lane;
-    const PBox me = load_pbox(L.c_box, L.c_af, jcol);
+    const PBox me = load_pbox(L.c_box, L.c_area, L.c_flag, jcol);
     const unsigned long long alive_rows = uniform64(~L.dead[rg]);
+    const unsigned long long reg_rows = uniform64(L.reg[rg]);
+    const bool cols_regular = ballot64(me.flag != (kFlagArea | kFlagRegular) && jcol < nc) == 0ull && !thr.slow_only;
     static_assert(ROWS % 4 == 0, "rows per item must be a multiple of 4");
     unsigned long long bits = 0ull;
     for (int i0 = 0; i0 < ROWS; i0 += 4) {
@@ -249,15 +360,30 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
       if (((alive_rows >> rl0) & 0xFull) == 0ull) continue;  // wave-uniform
       const int irow0 = rg * 64 + rl0;
       PBox rb[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) rb[u] = load_pbox(L.c_box, L.c_af, irow0 + u);
-      bool irr = false;
       bool bit[4];
+      if (cols_regular && ((reg_rows >> rl0) & 0xFull) == 0xFull) {  // wave-uniform: packed band filter
+        const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+        const float4 r0 = L.c_box[irow0], r1 = L.c_box[irow0 + 1], r2 = L.c_box[irow0 + 2], r3 = L.c_box[irow0 + 3];
+        const float4 ar = *reinterpret_cast<const float4 *>(L.c_area + irow0);
+        const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
+        bool irr = false;
+        nms_iou_gt_fast2(meb, me.area, r0, r1, a01, thr.thr, bit[0], bit[1], irr);
+        nms_iou_gt_fast2(meb, me.area, r2, r3, a23, thr.thr, bit[2], bit[3], irr);
+        if (__builtin_expect(ballot64(irr) != 0ull, 0)) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            bit[u] = nms_iou_gt(to_nbox(load_pbox(L.c_box, L.c_area, L.c_flag, irow0 + u)), to_nbox(me), thr.thr);
+        }
+      } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rb[u] = load_pbox(L.c_box, L.c_area, L.c_flag, irow0 + u);
+      bool irr = false;
 #pragma unroll
       for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, thr, irr);
       if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), thr.thr);
+      }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -280,6 +406,7 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
 #pragma unroll
     for (int g = 0; g < G; ++g) deadw[g] = uniform64(L.dead[g]);
     int cnt = nk;
+    int kreg = (nk == 0) ? 1 : L.s_nk[1];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int left = nc - g * 64;
@@ -313,13 +440,25 @@ __device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, in
           const int pos = cnt + __popcll(keptbits & lanemask_lt());
           const int j = g * 64 + lane;
           L.k_box[pos] = L.c_box[j];
-          L.k_af[pos] = L.c_af[j];
+          L.k_area[pos] = L.c_area[j];
+          L.k_flag[pos] = L.c_flag[j];
           L.k_idx[pos] = L.c_idx[j];
         }
         cnt += __popcll(keptbits);
+        if ((keptbits & ~uniform64(L.reg[g])) != 0ull) kreg = 0;
       }
     }
-    if (lane == 0) L.s_nk[0] = cnt;
+    // null boxes up to the next multiple of 4 (the packed kept-list tests read whole groups of four; the kept-list
+    // arrays hold a multiple of 4 entries)
+    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
+      L.k_box[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      L.k_area[cnt + lane] = 0.0f;
+      L.k_flag[cnt + lane] = 0;
+    }
+    if (lane == 0) {
+      L.s_nk[0] = cnt;
+      L.s_nk[1] = kreg;
+    }
   }
   __syncthreads();
   FRCNN_STAMP(13);

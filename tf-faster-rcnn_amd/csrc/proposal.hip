@@ -45,10 +45,11 @@ struct ProposalParams {
 
 template <int CH, int NT>
 static inline size_t proposal_lds_bytes(int Rc, int S) {
-  return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)(NT / 64) * 256 * 4 + 64 * 4;
+  return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)(NT / 64) * 256 * 4 + 64 * 4 +
+         (size_t)S * (16 + 8 + 4) + (size_t)S / 4;  // + the slice's decoded boxes, areas, flags, element indices, dead / regular words
 }
 
-// cache_keys: the image's N sort keys are held in LDS (after the other arrays) so that the radix-select
+// cache_keys = 1: the image's N sort keys are held in LDS (after the other arrays) so that the radix-select
 // passes and the compaction read LDS instead of re-reading the scores through L2.
 // NT = 1024: the whole CU works on the image (lowest latency; what the layers use when called one after the other).
 // NT = 256 ("small footprint", diagnostic knob FRCNN_PROPOSAL_THREADS=256): four waves and at most 128 VGPRs, the shape of a
@@ -57,7 +58,7 @@ static inline size_t proposal_lds_bytes(int Rc, int S) {
 // stage pipeline, so every entry point, the *_multi ones included, launches NT = 1024.
 template <int CH, int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
-void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
+void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_slices) {
   constexpr int kNT = NT, kNW = NT / 64;
   // One workgroup per image: latency bound.  When the stage pipeline runs it beside the chip-filling crop kernel, the
   // crop's waves on this CU must not take its issue slots (they cost the crop 1/16 of its CUs, this kernel 40 %).
@@ -72,7 +73,14 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
   int *misc = wsum + 32;                                       // [32]
   uint16_t *permA = reinterpret_cast<uint16_t *>(misc + 32);   // [S]
   // permB = permA + S                                         // [S] (ping-pong half)
-  uint32_t *kcache = reinterpret_cast<uint32_t *>(permA + 2 * S);  // [N] when cache_keys
+  float4 *sbox = reinterpret_cast<float4 *>(permA + 2 * S);    // [S] the slice in score order: corner-normalised boxes,
+  float *sarea = reinterpret_cast<float *>(sbox + S);          // [S] areas,
+  int *sflag = reinterpret_cast<int *>(sarea + S);             // [S] flags,
+  int *sidx = sflag + S;                                       // [S] element indices,
+  unsigned long long *sbad = reinterpret_cast<unsigned long long *>(sidx + S);  // [S/64] "fails the score threshold"
+  unsigned long long *sreg = sbad + S / 64;                    // [S/64] "regular box"
+  uint32_t *kcache = reinterpret_cast<uint32_t *>(sreg + S / 64);  // [N] when cache_keys == 1
+  uint16_t *kc16 = reinterpret_cast<uint16_t *>(kcache);           // [N] when cache_keys == 2: the keys' upper halves only
 
   const int tid = threadIdx.x;
   int b = blockIdx.x;
@@ -90,13 +98,19 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
   const float4 *anchors = reinterpret_cast<const float4 *>(p.anchors);
 
   FRCNN_STAMP(0);
-  if (cache_keys) {
+  if (tid == 0) misc[9] = 0;  // misc[9] = a bucket of the fast slice sort overflowed
+  if (cache_keys == 1) {
     for (int i = tid; i < N; i += kNT) kcache[i] = ~f_order_key(scores[i]);
-    __syncthreads();
+  } else if (cache_keys == 2) {
+    // N beyond what LDS holds as 32-bit keys (config 5: 35721): the fast slices decide membership from the upper 16 bits
+    // alone, so those are what is cached; the full key is fetched for the members of a slice only
+    for (int i = tid; i < N; i += kNT) kc16[i] = (uint16_t)(~f_order_key(scores[i]) >> 16);
   }
+  __syncthreads();
+  bool fast = fast_slices != 0;
   FRCNN_STAMP(1);
   auto keyf = [&](int i, uint32_t &k) -> bool {
-    k = cache_keys ? kcache[i] : ~f_order_key(scores[i]);
+    k = (cache_keys == 1) ? kcache[i] : ~f_order_key(scores[i]);
     return true;  // tf.nn.top_k ranks every element
   };
   auto box_of = [&](int i) -> float4 {
@@ -114,10 +128,148 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
 
   while (nk < R && consumed < K && !exhausted) {
     const int s_now = (K - consumed < S) ? (K - consumed) : S;
-    // ---- 1. key of rank consumed + s_now -----------------------------------------------------------
     uint32_t T2;
     int eq2;
     bool all;
+    int V;
+    bool in_place = false;  // the slice stands in keys[] / orig[] in score order (no permutation)
+    // ---- fast slices: any key boundary will do ------------------------------------------------------------------------
+    // The consumed prefix only has to be a prefix of the score order, not a fixed number of candidates.  (1) The boundary
+    // comes from a SAMPLE: two histogram passes over every 8th key that is not consumed yet give the 16-bit key prefix P
+    // below which about 11/16 of the slice capacity lies; what P really cuts off is then counted exactly.  (2) One sweep
+    // lists the members (upper key halves from LDS, ballots for the positions); (3) the members -- about one per thread --
+    // fetch their full keys and are BUCKET-sorted: 4 * NT buckets linear in the key over [lower bound, boundary], one LDS
+    // add per member that also hands back its place inside the bucket, a scan, the placement of (key, index), and an
+    // insertion sort by (key, index) inside the few buckets that hold more than one member -- the index as second key is
+    // tf.nn.top_k's "lower index first", so no index-ordered compaction and no stable sort are needed.  Anything unusual
+    // (the cut holds more than the slice's capacity or crosses rank K, a bucket with more than 32 members: many equal or
+    // tightly clustered scores) takes the exact selection + stable radix sort below, from then on.
+    if (fast) {
+      const int lane = tid & 63, w = tid >> 6;
+      const unsigned long long lt = lanemask_lt();
+      const uint32_t lo16 = T1 >> 16;  // T1 is a multiple of 65536 on this path
+      auto k16 = [&](int i) -> uint32_t {
+        return (cache_keys == 2) ? (uint32_t)kc16[i] : ((cache_keys == 1) ? kcache[i] : ~f_order_key(scores[i])) >> 16;
+      };
+      auto key_sample = [&](int j, uint32_t &k) -> bool {
+        const uint32_t t = k16(j << 3);
+        k = t << 16;
+        return t >= lo16;
+      };
+      uint32_t P, low_byte;
+      int cnt_s;
+      bool allp;
+      const int target = (s_now * 11) >> 4;
+      prefix16_select<NT>(key_sample, (N + 7) >> 3, (target >> 3) > 0 ? (target >> 3) : 1, hist, misc, P, cnt_s, allp, low_byte);
+      const uint32_t hi16 = allp ? 0xFFFFu : P;
+      const uint32_t hi = (hi16 << 16) | 0xFFFFu;
+      // exact count of the cut, per wave (uniform trip count: the ballots need every lane)
+      const int n_up = (N + kNT - 1) / kNT * kNT;
+      int wc = 0;
+      for (int i = tid; i < n_up; i += kNT) {
+        uint32_t t = 0;
+        if (i < N) t = k16(i);
+        wc += __popcll(ballot64(i < N && t >= lo16 && t <= hi16));
+      }
+      __syncthreads();  // wsum may still be read by the selection
+      if (lane == 0) wsum[w] = wc;
+      __syncthreads();
+      int base = 0, Vf = 0;
+#pragma unroll
+      for (int ww = 0; ww < kNW; ++ww) {
+        base += (ww < w) ? wsum[ww] : 0;
+        Vf += wsum[ww];
+      }
+      FRCNN_STAMP(2);
+      if (Vf > s_now || Vf < 1) {
+        fast = false;
+      } else {
+        constexpr int NBK = 4 * kNT;  // = the histogram array
+        int *mlist = sidx;                                     // [Vf] member element indices (the slice arrays are free here)
+        uint32_t *mkey = reinterpret_cast<uint32_t *>(sbox);   // [Vf] their keys
+        // a lower bound of the slice's keys: exact from the second slice on, for the first the sample's lowest top byte
+        // (a member below it lands in bucket 0: the mapping stays monotone)
+        const uint32_t kmin = T1 > (low_byte << 24) ? T1 : (low_byte << 24);
+        const uint32_t span = hi - kmin;
+        const float scale = (float)NBK / ((float)span + 1.0f);
+        auto bucket_of = [&](uint32_t k) -> int {
+          const int bkt = (k > kmin) ? (int)((float)(k - kmin) * scale) : 0;  // monotone in k
+          return bkt < NBK - 1 ? bkt : NBK - 1;
+        };
+        for (int i = tid; i < NBK; i += kNT) hist[i] = 0;
+        {
+          int pos = base;
+          for (int i = tid; i < n_up; i += kNT) {
+            uint32_t t = 0;
+            if (i < N) t = k16(i);
+            const bool m = i < N && t >= lo16 && t <= hi16;
+            const unsigned long long bal = ballot64(m);
+            if (m) mlist[pos + __popcll(bal & lt)] = i;
+            pos += __popcll(bal);
+          }
+        }
+        __syncthreads();
+        for (int j = tid; j < Vf; j += kNT) {
+          uint32_t k;
+          keyf(mlist[j], k);
+          mkey[j] = k;
+          permA[j] = (uint16_t)atomicAdd(&hist[bucket_of(k)], 1u);  // place inside the bucket (arrival order)
+        }
+        __syncthreads();
+        {
+          const uint32_t a0 = hist[4 * tid], a1 = hist[4 * tid + 1], a2 = hist[4 * tid + 2], a3 = hist[4 * tid + 3];
+          int total;
+          const int ex = block_excl_scan<NT>((int)(a0 + a1 + a2 + a3), wsum, total);
+          hist[4 * tid] = (uint32_t)ex;
+          hist[4 * tid + 1] = (uint32_t)ex + a0;
+          hist[4 * tid + 2] = (uint32_t)ex + a0 + a1;
+          hist[4 * tid + 3] = (uint32_t)ex + a0 + a1 + a2;
+          if (((a0 > a1 ? a0 : a1) > 32u) || ((a2 > a3 ? a2 : a3) > 32u)) misc[9] = 1;
+        }
+        __syncthreads();
+        if (misc[9]) {
+          fast = false;  // (misc[9] stays set: the fast path is not tried again)
+        } else {
+          for (int j = tid; j < Vf; j += kNT) {
+            const uint32_t k = mkey[j];
+            const uint32_t at = hist[bucket_of(k)] + permA[j];
+            keys[at] = k;
+            orig[at] = (uint32_t)mlist[j];
+          }
+          __syncthreads();
+          // bucket b starts at hist[b] and ends where b + 1 starts
+          {
+            uint32_t begin = hist[4 * tid];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint32_t end = (4 * tid + u + 1 < NBK) ? hist[4 * tid + u + 1] : (uint32_t)Vf;
+              for (uint32_t a = begin + 1; a < end; ++a) {
+                const uint32_t kk = keys[a], oo = orig[a];
+                uint32_t c = a;
+                while (c > begin && (keys[c - 1] > kk || (keys[c - 1] == kk && orig[c - 1] > oo))) {
+                  keys[c] = keys[c - 1];
+                  orig[c] = orig[c - 1];
+                  --c;
+                }
+                keys[c] = kk;
+                orig[c] = oo;
+              }
+              begin = end;
+            }
+          }
+          V = Vf;
+          in_place = true;
+          T2 = hi + 1u;  // the consumed prefix is {key < T2}; hi = 0xFFFFFFFF ends the loop below
+          eq2 = 0;
+          all = hi == 0xFFFFFFFFu;
+          if (all || consumed + V >= N) exhausted = true;
+          __syncthreads();
+          FRCNN_STAMP(4);
+        }
+      }
+    }
+    if (!in_place) {
+    // ---- 1. key of rank consumed + s_now -----------------------------------------------------------
     radix_select<NT>(keyf, N, consumed + s_now, hist, misc, T2, eq2, all);
     FRCNN_STAMP(2);
     if (all) {  // cannot happen while K <= N; kept for safety
@@ -126,8 +278,7 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
       exhausted = true;
     }
     // ---- 2. compact the slice (in2 and not in1) in index order --------------------------------------
-    int V;
-    if (cache_keys) {
+    if (cache_keys == 1) {
       // keys in LDS: every thread owns a contiguous run of elements
       int e1 = 0, e2 = 0;
       for (int i = i0; i < i1; ++i) {
@@ -284,20 +435,57 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys) {
     const int soff = block_sort_digits<NT>([&](int slot, int pass) -> uint32_t { return keys[slot] >> (8 * pass); }, npass, permA, S,
                                        V, hist, wsum);
     const uint16_t *perm = permA + soff;
+    for (int j = tid; j < V; j += kNT) sidx[j] = (int)orig[perm[j]];
+    if (V < s_now) exhausted = true;
+    __syncthreads();
     FRCNN_STAMP(4);
-    // ---- 4. greedy NMS over the slice ------------------------------------------------------------------
+    }  // exact slice
+    // ---- 4. decode the slice's boxes, all threads at once (one round of global-memory latency per slice) ------------
+    {
+      const int v_up = (V + CH - 1) / CH * CH;  // whole chunks: the tail is read by the tiles, never used
+      for (int j = tid; j < v_up; j += kNT) {   // v_up <= S: S is a multiple of 256; whole waves: v_up is a multiple of 64
+        NBox nb;
+        nb.ymin = nb.xmin = nb.ymax = nb.xmax = nb.area = 0.0f;
+        int ei = -1, fl = 0;
+        bool bad = false;
+        if (j < V) {
+          ei = in_place ? (int)orig[j] : sidx[j];
+          const float4 box = box_of(ei);
+          bad = !(scores[ei] > p.score_thr);
+          nb = normalise_box(box);
+          fl = box_flags(box, nb);
+        }
+        sbox[j] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
+        sarea[j] = nb.area;
+        sflag[j] = fl;
+        sidx[j] = ei;
+        const unsigned long long badw = ballot64(bad);
+        const unsigned long long regw = ballot64(fl == (kFlagArea | kFlagRegular));
+        if ((tid & 63) == 0) {
+          sbad[j >> 6] = badw;
+          sreg[j >> 6] = regw;
+        }
+      }
+      __syncthreads();
+    }
+    FRCNN_STAMP(5);
+    // ---- 5. greedy NMS over the slice ------------------------------------------------------------------
     for (int cbase = 0; cbase < V && nk < R; cbase += CH) {
       const int nc = (V - cbase < CH) ? (V - cbase) : CH;
-      nk = nms_chunk<NT, CH>(L, nc, nk, R, p.iou, [&](int j, float4 &box, int &ei, bool &bad) {
-        ei = (int)orig[perm[cbase + j]];
-        box = box_of(ei);
-        bad = !(scores[ei] > p.score_thr);
-      });
+      NmsLds<CH> Lc = L;
+      Lc.c_box = sbox + cbase;
+      Lc.c_area = sarea + cbase;
+      Lc.c_flag = sflag + cbase;
+      Lc.c_idx = sidx + cbase;
+      if (tid < CH / 64) {
+        L.dead[tid] = sbad[(cbase >> 6) + tid];
+        L.reg[tid] = sreg[(cbase >> 6) + tid];
+      }
+      nk = nms_chunk_resolve<NT, CH>(Lc, nc, nk, R, p.iou);
     }
     consumed += V;
     T1 = T2;
     eq1 = eq2;
-    if (V < s_now) exhausted = true;
   }
 
   // ---- outputs: (B,R,4) clipped, score-ordered, zero padded ----------------------------------------
@@ -324,14 +512,16 @@ template <int CH, int NT>
 static int launch_proposal_t(ProposalParams &p, int B, int Rc, int S, hipStream_t stream, bool *handled) {
   size_t lds = proposal_lds_bytes<CH, NT>(Rc, S);
   if (lds > 160 * 1024) return FRCNN_OK;  // does not fit: the caller takes the unfused path
-  const int cache_keys = (lds + (size_t)p.N * 4 <= 160 * 1024) ? 1 : 0;
-  if (cache_keys) lds += (size_t)p.N * 4;
+  const int cache_keys = (lds + (size_t)p.N * 4 <= 160 * 1024) ? 1 : (lds + round_up((size_t)p.N * 2, 16) <= 160 * 1024) ? 2 : 0;
+  if (cache_keys == 1) lds += (size_t)p.N * 4;
+  if (cache_keys == 2) lds += round_up((size_t)p.N * 2, 16);
   auto kern = proposal_kernel<CH, NT>;
   if (lds > 48 * 1024) {
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NT), lds, stream, p, Rc, S, cache_keys);
+  const int fast_slices = knob(kKnobProposalExactSlices, 0) ? 0 : 1;  // FRCNN_PROPOSAL_EXACT_SLICES=1: exact selection only
+  hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(NT), lds, stream, p, Rc, S, cache_keys, fast_slices);
   *handled = true;
   return check_launch("roi_bbox (fused proposal kernel)");
 }
@@ -373,16 +563,17 @@ int launch_proposal(const float *const *deltas, const float *const *scores, int 
   p.R = R_nms;
   p.iou = make_iou_thr(iou_thr);
   p.score_thr = -__builtin_huge_valf();
-  // chunk width: tuning knob (FRCNN_PROPOSAL_CHUNK = 64 | 128 | 256), default 128
-  const int ch = knob(kKnobProposalChunk, 128);
+  // chunk width: tuning knob (FRCNN_PROPOSAL_CHUNK = 64 | 128 | 256); 64 since the packed pair tests (cfg2: 44.8 us per 16
+  // images against 45.9 at 128 and 47.2 at 256; clustered proposals 53.8 / 59.7 / 64.7)
+  const int ch = knob(kKnobProposalChunk, 64);
   if (knob_set(kKnobProposalThreads)) small_footprint = knob(kKnobProposalThreads, 0) == 256;  // diagnostic override
   if (small_footprint) {
-    if (ch == 64) return launch_proposal_t<64, 256>(p, B, Rc, S, stream, handled);
-    return launch_proposal_t<128, 256>(p, B, Rc, S, stream, handled);
+    if (ch == 128) return launch_proposal_t<128, 256>(p, B, Rc, S, stream, handled);
+    return launch_proposal_t<64, 256>(p, B, Rc, S, stream, handled);
   }
-  if (ch == 64) return launch_proposal_t<64, 1024>(p, B, Rc, S, stream, handled);
+  if (ch == 128) return launch_proposal_t<128, 1024>(p, B, Rc, S, stream, handled);
   if (ch == 256) return launch_proposal_t<256, 1024>(p, B, Rc, S, stream, handled);
-  return launch_proposal_t<128, 1024>(p, B, Rc, S, stream, handled);
+  return launch_proposal_t<64, 1024>(p, B, Rc, S, stream, handled);
 }
 
 }  // namespace frcnn
