@@ -139,19 +139,19 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
   __syncthreads();
 }
 
-// The two upper passes of radix_select only: P = the smallest 16-bit prefix such that at least `need` valid keys have
-// (key >> 16) <= P, and cnt_le = how many valid keys that is (>= need; the surplus is what the prefix's bin holds beyond
-// the rank asked for).  all = true when fewer than `need` valid keys exist (then P = 0xFFFF and cnt_le = their number).
-// low_byte = the smallest top byte any valid key has (0 when there is none): low_byte << 24 bounds every key from below.
-// misc: >= 5 ints.
-// Half the passes of the exact selection, for callers that may cut their slice at any key boundary near a rank.
+// The two upper passes of a radix selection, for SMALL n (a sample of the keys): P = the smallest 16-bit prefix such
+// that at least `need` valid keys have (key >> 16) <= P, and cnt_le = how many valid keys that is (>= need; the surplus
+// is what the prefix's bin holds beyond the rank asked for).  all = true when fewer than `need` valid keys exist (then
+// P = 0xFFFF and cnt_le = their number).  low_byte = the smallest top byte any valid key has (0 when there is none):
+// low_byte << 24 bounds every valid key from below.  One 256-bin histogram shared by the waves (the top byte through
+// wave-aggregated adds), three barriers per pass.  hist: 256 uint32 of LDS, misc: >= 5 ints.
 template <int NT = kNT, class KeyF>
 __device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint32_t *hist, int *misc, uint32_t &P,
                                                 int &cnt_le, bool &all, uint32_t &low_byte) {
-  constexpr int kNT = NT, kNW = NT / 64;
-  static_assert(NT >= 256 && NT % 64 == 0, "prefix16_select: the 256 bins are summed by the first 256 threads");
+  constexpr int kNT = NT;
+  static_assert(NT >= 256 && NT % 64 == 0, "prefix16_select: the 256 bins are cleared by the first 256 threads");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  __syncthreads();
+  __syncthreads();  // hist / misc may still be read by what came before
   if (tid == 0) misc[2] = 0;
   uint32_t prefix = 0;
   int below = 0;  // valid keys whose prefix is smaller than the bin chosen so far
@@ -159,28 +159,20 @@ __device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint
   cnt_le = 0;
   for (int pass = 1; pass >= 0; --pass) {
     const int shift = 16 + pass * 8;
-    for (int i = tid; i < kNW * 256; i += kNT) hist[i] = 0;
+    if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    uint32_t *myhist = hist + w * 256;
     if (pass == 1) {
-      const int n_up = (n + kNT - 1) / kNT * kNT;
+      const int n_up = (n + kNT - 1) / kNT * kNT;  // uniform trip count for the ballots
       for (int i = tid; i < n_up; i += kNT) {
         uint32_t k = 0;
         const bool v = (i < n) && keyf(i, k);
-        hist_add(myhist, (k >> shift) & 255u, v);
+        hist_add(hist, (k >> shift) & 255u, v);
       }
     } else {
       for (int i = tid; i < n; i += kNT) {
         uint32_t k = 0;
-        if (keyf(i, k) && (k >> 24) == prefix) atomicAdd(&myhist[(k >> shift) & 255u], 1u);
+        if (keyf(i, k) && (k >> 24) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
       }
-    }
-    __syncthreads();
-    if (tid < 256) {
-      uint32_t sum = 0;
-#pragma unroll
-      for (int ww = 0; ww < kNW; ++ww) sum += hist[ww * 256 + tid];
-      hist[tid] = sum;
     }
     __syncthreads();
     if (w == 0) {
@@ -228,6 +220,7 @@ __device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint
       }
     }
     __syncthreads();
+    // (misc is next written two barriers from here, hist cleared by threads that are past this one)
     if (misc[2]) {  // only possible in the first pass (the second looks inside a bin that holds the rank)
       all = true;
       prefix = 0xFFFFu;
@@ -238,11 +231,9 @@ __device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint
     cnt_le = below + misc[3];
     below += misc[1];
     need -= misc[1];
-    __syncthreads();  // misc is rewritten by the next pass
   }
   P = prefix;
   low_byte = (uint32_t)misc[4];
-  __syncthreads();
 }
 
 // Stable least-significant-digit radix sort of V slot numbers: `npass` passes of 8 bits, digit(slot, pass)

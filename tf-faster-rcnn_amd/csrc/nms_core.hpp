@@ -465,4 +465,231 @@ __device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, in
   return L.s_nk[0];
 }
 
+// ---- a whole pre-decoded slice in chunks of 64, two barriers per chunk (the fused RoIBBox kernel) --------------------------
+// The slice's candidates stand in LDS in priority order: sbox / sarea / sflag / sidx, per 64 the words sbad ("fails the score
+// threshold") and sreg ("regular box"); the arrays are filled (zero boxes) up to a multiple of 64.  Against nms_chunk_resolve
+// at CH = 64: the intra-chunk tile of chunk c + 1 does not depend on chunk c's outcome, so waves 1.. compute it while wave 0
+// resolves chunk c (partial column words go to a double-buffered array of 16-bit pieces, one per (wave item, column): no
+// zeroing, no atomics); the kept-list tests of a chunk OR their ballots into a word that wave 0 preset with sbad.
+struct Slice64Lds {
+  unsigned long long *dead;  // [2]  dead word of the current / next chunk
+  uint16_t *part;            // [2][NT / 64][64]  partial column words: rows item * (4096 / NT) ... of the chunk's tile
+  int *s_nk;                 // [4]  [0] kept count, [1] every kept box so far is regular
+};
+template <int NT>
+__host__ __device__ static inline size_t slice64_lds_bytes() {
+  return 2 * 8 + 2 * (size_t)(NT / 64) * 64 * 2 + 4 * 4;
+}
+
+struct KeptLds {
+  float4 *box;  // [Rc] (Rc a multiple of 4; null boxes from the kept count up to the next multiple of 4)
+  float *area;
+  int *flag;
+  int *idx;
+};
+
+// "some kept box of this wave's share suppresses me": the share is groups `first`, first + step, ... of four kept boxes.
+__device__ __forceinline__ bool kept_list_hits(const KeptLds &K, const PBox &me, bool live, int first, int step, int nk,
+                                               bool all_regular, const IouThr &thr) {
+  bool d = false;
+  const int ngroups = (nk + 3) >> 2;
+  if (all_regular) {
+    const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+    for (int g4 = first; g4 < ngroups; g4 += step) {
+      const float4 *kb = K.box + 4 * g4;
+      const float4 b0 = kb[0], b1 = kb[1], b2 = kb[2], b3 = kb[3];
+      const float4 ar = *reinterpret_cast<const float4 *>(K.area + 4 * g4);
+      const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
+      bool y0, y1, y2, y3, irr = false;
+      nms_iou_gt_fast2(meb, me.area, b0, b1, a01, thr.thr, y0, y1, irr);
+      nms_iou_gt_fast2(meb, me.area, b2, b3, a23, thr.thr, y2, y3, irr);
+      bool dd = y0 | y1 | y2 | y3;
+      if (__builtin_expect(ballot64(irr && live) != 0ull, 0)) {  // inside the band: the reference formulation
+        const NBox men = to_nbox(me);
+        const float4 bb[4] = {b0, b1, b2, b3};
+        const float aa[4] = {ar.x, ar.y, ar.z, ar.w};
+        dd = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          NBox kn;
+          kn.ymin = bb[u].x;
+          kn.xmin = bb[u].y;
+          kn.ymax = bb[u].z;
+          kn.xmax = bb[u].w;
+          kn.area = aa[u];
+          dd = dd | nms_iou_gt(men, kn, thr.thr);
+        }
+      }
+      d = d | dd;
+      if (ballot64(live && !d) == 0ull) break;
+    }
+  } else {
+    for (int g4 = first; g4 < ngroups; g4 += step) {
+      PBox kb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kb[u] = load_pbox(K.box, K.area, K.flag, 4 * g4 + u);  // (null boxes carry flag 0)
+      bool irr = false, dd = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], thr, irr);
+      if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
+        dd = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), thr.thr);
+      }
+      d = d | dd;
+      if (ballot64(live && !d) == 0ull) break;
+    }
+  }
+  return d;
+}
+
+// bits u = "row irow0 + u suppresses me" for four consecutive rows (IoU only: the caller masks order and validity)
+__device__ __forceinline__ uint32_t tile_rows4(const float4 *box, const float *area, const int *flag, int irow0, const PBox &me,
+                                               bool packed, const IouThr &thr) {
+  bool bit[4];
+  if (packed) {  // wave-uniform: the four rows and every live column are regular
+    const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+    const float4 r0 = box[irow0], r1 = box[irow0 + 1], r2 = box[irow0 + 2], r3 = box[irow0 + 3];
+    const float4 ar = *reinterpret_cast<const float4 *>(area + irow0);
+    const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
+    bool irr = false;
+    nms_iou_gt_fast2(meb, me.area, r0, r1, a01, thr.thr, bit[0], bit[1], irr);
+    nms_iou_gt_fast2(meb, me.area, r2, r3, a23, thr.thr, bit[2], bit[3], irr);
+    if (__builtin_expect(ballot64(irr) != 0ull, 0)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(load_pbox(box, area, flag, irow0 + u)), to_nbox(me), thr.thr);
+    }
+  } else {
+    PBox rb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) rb[u] = load_pbox(box, area, flag, irow0 + u);
+    bool irr = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, thr, irr);
+    if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), thr.thr);
+    }
+  }
+  return (uint32_t)bit[0] | ((uint32_t)bit[1] << 1) | ((uint32_t)bit[2] << 2) | ((uint32_t)bit[3] << 3);
+}
+
+// Returns the new kept count.  Must be called by all NT threads; the slice arrays must be published (a barrier behind
+// their last write).  V <= the arrays' filled length; nk may be > 0 (earlier slices).
+template <int NT>
+__device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sarea, const int *sflag, const int *sidx,
+                                           const unsigned long long *sbad, const unsigned long long *sreg, int V,
+                                           const KeptLds &K, const Slice64Lds &T, int nk, int R, const IouThr &thr) {
+  constexpr int NWV = NT / 64;
+  constexpr int ROWS = 64 / NWV;  // rows of a tile per work item: 4 (16 waves) ... 16 (4 waves)
+  static_assert(NWV >= 4 && NWV <= 16 && ROWS % 4 == 0, "nms_slice64: 4 to 16 waves");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int nchunks = (V + 63) >> 6;
+  const int kRegular = kFlagArea | kFlagRegular;
+
+  // rows [item * ROWS, +ROWS) of chunk c's diagonal tile against column `lane` -> part[c & 1][item][lane]
+  auto tile_item = [&](int c, int item) {
+    const int cbase = c << 6;
+    const int nc = (V - cbase < 64) ? (V - cbase) : 64;
+    const int r0 = item * ROWS;
+    uint32_t bits = 0;
+    if (r0 + 1 < nc) {  // wave-uniform: some row of the item has a later live column
+      const PBox me = load_pbox(sbox, sarea, sflag, cbase + lane);
+      const unsigned long long regw = uniform64(sreg[c]);
+      const bool cols_regular = ballot64(me.flag != kRegular && lane < nc) == 0ull && !thr.slow_only;
+#pragma unroll
+      for (int i0 = 0; i0 < ROWS; i0 += 4) {
+        const bool packed = cols_regular && ((regw >> (r0 + i0)) & 0xFull) == 0xFull;
+        bits |= tile_rows4(sbox, sarea, sflag, cbase + r0 + i0, me, packed, thr) << i0;
+      }
+      // row r0 + u counts for column `lane` when it comes before it; columns beyond the chunk's end count for nothing
+      const int before = lane - r0;  // rows r0 .. r0 + before - 1 precede the column
+      const uint32_t order = before <= 0 ? 0u : (before >= ROWS ? ((1u << ROWS) - 1u) : ((1u << before) - 1u));
+      bits &= (lane < nc) ? order : 0u;
+    }
+    T.part[((c & 1) * NWV + item) * 64 + lane] = (uint16_t)bits;
+  };
+
+  if (nchunks > 0) tile_item(0, w);
+  if (tid == 0) {
+    T.dead[0] = sbad[0];
+    T.s_nk[0] = nk;
+    if (nk == 0) T.s_nk[1] = 1;
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks && nk < R; ++c) {
+    const int cbase = c << 6;
+    const int nc = (V - cbase < 64) ? (V - cbase) : 64;
+    // ---- a. the chunk against the kept list: wave w takes the groups w, w + NWV, ... of four kept boxes -------------
+    if (nk > 0) {
+      const PBox me = load_pbox(sbox, sarea, sflag, cbase + lane);
+      const unsigned long long valid_w = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
+      const unsigned long long already = uniform64(sbad[c]);
+      const bool live = ((valid_w & ~already) >> lane) & 1ull;
+      const bool all_regular = T.s_nk[1] != 0 && (uniform64(~sreg[c]) & valid_w) == 0ull && !thr.slow_only;
+      const bool d = kept_list_hits(K, me, live, w, NWV, nk, all_regular, thr);
+      const unsigned long long word = ballot64(d && live);
+      if (lane == 0 && word != 0ull) atomicOr(&T.dead[c & 1], word);
+    }
+    __syncthreads();
+    FRCNN_STAMP(11);
+    if (w == 0) {
+      // ---- c. greedy resolve of the chunk in parallel rounds (see nms_chunk_resolve) ---------------------------------
+      const unsigned long long deadw = uniform64(T.dead[c & 1]);
+      const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
+      unsigned long long col = 0ull;
+#pragma unroll
+      for (int it = 0; it < NWV; ++it)
+        col |= (unsigned long long)T.part[((c & 1) * NWV + it) * 64 + lane] << (it * ROWS);
+      unsigned long long und = ~deadw & valid;
+      unsigned long long keptbits = 0ull;
+      while (und != 0ull) {
+        const bool in1 = (und >> lane) & 1ull;
+        und &= ~ballot64(in1 && (col & keptbits) != 0ull);
+        const bool in2 = (und >> lane) & 1ull;
+        const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
+        keptbits |= k;
+        und &= ~k;
+      }
+      int cnt = nk;
+      if (cnt + __popcll(keptbits) > R) {  // the greedy scan stops at R: keep the first R - cnt of them
+        unsigned long long t = 0ull, bb = keptbits;
+        for (int k = cnt; k < R; ++k) {
+          const unsigned long long low = bb & (0ull - bb);
+          t |= low;
+          bb ^= low;
+        }
+        keptbits = t;
+      }
+      if ((keptbits >> lane) & 1ull) {
+        const int pos = cnt + __popcll(keptbits & lanemask_lt());
+        const int j = cbase + lane;
+        K.box[pos] = sbox[j];
+        K.area[pos] = sarea[j];
+        K.flag[pos] = sflag[j];
+        K.idx[pos] = sidx[j];
+      }
+      cnt += __popcll(keptbits);
+      if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {  // null boxes up to the next multiple of 4
+        K.box[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        K.area[cnt + lane] = 0.0f;
+        K.flag[cnt + lane] = 0;
+      }
+      if (lane == 0) {
+        T.s_nk[0] = cnt;
+        if ((keptbits & ~uniform64(sreg[c])) != 0ull) T.s_nk[1] = 0;
+        if (c + 1 < nchunks) T.dead[(c + 1) & 1] = sbad[c + 1];
+      }
+    } else if (c + 1 < nchunks) {
+      // ---- b. meanwhile: the next chunk's tile, items 0 .. NWV - 1 over the waves 1 .. NWV - 1 (wave 1 takes two) ------
+      tile_item(c + 1, w - 1);
+      if (w == 1) tile_item(c + 1, NWV - 1);
+    }
+    __syncthreads();
+    FRCNN_STAMP(13);
+    nk = T.s_nk[0];
+  }
+  return nk;
+}
+
 }  // namespace frcnn

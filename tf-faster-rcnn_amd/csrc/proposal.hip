@@ -46,7 +46,8 @@ struct ProposalParams {
 template <int CH, int NT>
 static inline size_t proposal_lds_bytes(int Rc, int S) {
   return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)(NT / 64) * 256 * 4 + 64 * 4 +
-         (size_t)S * (16 + 8 + 4) + (size_t)S / 4;  // + the slice's decoded boxes, areas, flags, element indices, dead / regular words
+         (size_t)S * (16 + 8 + 4) + (size_t)S / 4 +  // + the slice's decoded boxes, areas, flags, element indices, dead / regular words
+         round_up(slice64_lds_bytes<NT>(), 16);
 }
 
 // cache_keys = 1: the image's N sort keys are held in LDS (after the other arrays) so that the radix-select
@@ -79,7 +80,12 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
   int *sidx = sflag + S;                                       // [S] element indices,
   unsigned long long *sbad = reinterpret_cast<unsigned long long *>(sidx + S);  // [S/64] "fails the score threshold"
   unsigned long long *sreg = sbad + S / 64;                    // [S/64] "regular box"
-  uint32_t *kcache = reinterpret_cast<uint32_t *>(sreg + S / 64);  // [N] when cache_keys == 1
+  Slice64Lds T64;
+  T64.dead = sreg + S / 64;
+  T64.part = reinterpret_cast<uint16_t *>(T64.dead + 2);
+  T64.s_nk = reinterpret_cast<int *>(T64.part + 2 * kNW * 64);
+  uint32_t *kcache = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sreg + S / 64) +
+                                                  ((slice64_lds_bytes<NT>() + 15) & ~(size_t)15));  // [N] when cache_keys == 1
   uint16_t *kc16 = reinterpret_cast<uint16_t *>(kcache);           // [N] when cache_keys == 2: the keys' upper halves only
 
   const int tid = threadIdx.x;
@@ -107,7 +113,7 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
     for (int i = tid; i < N; i += kNT) kc16[i] = (uint16_t)(~f_order_key(scores[i]) >> 16);
   }
   __syncthreads();
-  bool fast = fast_slices != 0;
+  bool fast = fast_slices != 0 && N <= 64 * kNT;  // (a thread's elements are the bits of one 64-bit mask)
   FRCNN_STAMP(1);
   auto keyf = [&](int i, uint32_t &k) -> bool {
     k = (cache_keys == 1) ? kcache[i] : ~f_order_key(scores[i]);
@@ -145,8 +151,6 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
     // (the cut holds more than the slice's capacity or crosses rank K, a bucket with more than 32 members: many equal or
     // tightly clustered scores) takes the exact selection + stable radix sort below, from then on.
     if (fast) {
-      const int lane = tid & 63, w = tid >> 6;
-      const unsigned long long lt = lanemask_lt();
       const uint32_t lo16 = T1 >> 16;  // T1 is a multiple of 65536 on this path
       auto k16 = [&](int i) -> uint32_t {
         return (cache_keys == 2) ? (uint32_t)kc16[i] : ((cache_keys == 1) ? kcache[i] : ~f_order_key(scores[i])) >> 16;
@@ -163,23 +167,26 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
       prefix16_select<NT>(key_sample, (N + 7) >> 3, (target >> 3) > 0 ? (target >> 3) : 1, hist, misc, P, cnt_s, allp, low_byte);
       const uint32_t hi16 = allp ? 0xFFFFu : P;
       const uint32_t hi = (hi16 << 16) | 0xFFFFu;
-      // exact count of the cut, per wave (uniform trip count: the ballots need every lane)
-      const int n_up = (N + kNT - 1) / kNT * kNT;
-      int wc = 0;
-      for (int i = tid; i < n_up; i += kNT) {
-        uint32_t t = 0;
-        if (i < N) t = k16(i);
-        wc += __popcll(ballot64(i < N && t >= lo16 && t <= hi16));
-      }
-      __syncthreads();  // wsum may still be read by the selection
-      if (lane == 0) wsum[w] = wc;
-      __syncthreads();
-      int base = 0, Vf = 0;
-#pragma unroll
-      for (int ww = 0; ww < kNW; ++ww) {
-        base += (ww < w) ? wsum[ww] : 0;
-        Vf += wsum[ww];
-      }
+      // One sweep over the upper key halves: every thread notes which of its (strided) elements the cut holds as bits of a
+      // 64-bit mask -- no ballots, so the compiler keeps the loads in flight -- and a block scan of the counts gives each
+      // thread its place in the member list.  (The kind of key cache is chosen outside the loop: a branch per element
+      // would sit between the loads.)
+      unsigned long long mine = 0ull;
+      auto members_from = [&](auto load16) {
+        int c = 0;
+        for (int i = tid; i < N; i += kNT, ++c) {
+          const uint32_t t = load16(i);
+          mine |= (unsigned long long)(t >= lo16 && t <= hi16) << c;
+        }
+      };
+      if (cache_keys == 2)
+        members_from([&](int i) -> uint32_t { return (uint32_t)kc16[i]; });
+      else if (cache_keys == 1)
+        members_from([&](int i) -> uint32_t { return kcache[i] >> 16; });
+      else
+        members_from([&](int i) -> uint32_t { return ~f_order_key(scores[i]) >> 16; });
+      int Vf;
+      const int base = block_excl_scan<NT>(__popcll(mine), wsum, Vf);
       FRCNN_STAMP(2);
       if (Vf > s_now || Vf < 1) {
         fast = false;
@@ -199,13 +206,9 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
         for (int i = tid; i < NBK; i += kNT) hist[i] = 0;
         {
           int pos = base;
-          for (int i = tid; i < n_up; i += kNT) {
-            uint32_t t = 0;
-            if (i < N) t = k16(i);
-            const bool m = i < N && t >= lo16 && t <= hi16;
-            const unsigned long long bal = ballot64(m);
-            if (m) mlist[pos + __popcll(bal & lt)] = i;
-            pos += __popcll(bal);
+          while (mine != 0ull) {
+            mlist[pos++] = tid + (int)__builtin_ctzll(mine) * kNT;
+            mine &= mine - 1ull;
           }
         }
         __syncthreads();
@@ -470,6 +473,14 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
     }
     FRCNN_STAMP(5);
     // ---- 5. greedy NMS over the slice ------------------------------------------------------------------
+    if (CH == 64) {
+      KeptLds kept;
+      kept.box = L.k_box;
+      kept.area = L.k_area;
+      kept.flag = L.k_flag;
+      kept.idx = L.k_idx;
+      nk = nms_slice64<NT>(sbox, sarea, sflag, sidx, sbad, sreg, V, kept, T64, nk, R, p.iou);
+    } else
     for (int cbase = 0; cbase < V && nk < R; cbase += CH) {
       const int nc = (V - cbase < CH) ? (V - cbase) : CH;
       NmsLds<CH> Lc = L;
