@@ -53,23 +53,32 @@ static const int kDecMaxClasses = 256;
 // per-NMS-wave LDS: one 64-candidate tile + the kept list of the class being processed
 __host__ __device__ static inline size_t dec_wave_bytes(int Rpc4) { return (size_t)(64 + Rpc4) * 24; }
 
-__host__ __device__ static inline size_t dec_lds_bytes(int Vcap, int Rpc4, int nms_waves, int nt) {
+// the small-V schedule's arrays (they share the wave areas' space: a launch takes one schedule or the other per image):
+// corner-normalised box, original box, (area, flags), sorted position of a kept entry, slot of a sorted position
+__host__ __device__ static inline size_t dec_small_bytes(int capV) { return (size_t)capV * (16 + 16 + 8 + 2 + 2); }
+
+__host__ __device__ static inline size_t dec_area_bytes(int Rpc4, int nms_waves, int capV) {
+  const size_t a = (size_t)nms_waves * dec_wave_bytes(Rpc4), b = dec_small_bytes(capV);
+  return ((a > b ? a : b) + 15) & ~(size_t)15;
+}
+
+__host__ __device__ static inline size_t dec_lds_bytes(int Vcap, int Rpc4, int nms_waves, int nt, int capV) {
   return (size_t)Vcap * (4 + 4 + 2 + 2 + 2) + (size_t)(nt / 64) * 256 * 4 + 64 * 4 + (size_t)3 * (kDecMaxClasses + 4) * 4 +
-         (size_t)nms_waves * dec_wave_bytes(Rpc4);
+         dec_area_bytes(Rpc4, nms_waves, capV);
 }
 
 // NT = 1024: lowest latency; NT = 256: the small-footprint schedule of the stage pipeline (see proposal.hip).
 template <int NT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1)))
-void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
+void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV) {
   constexpr int kNT = NT, kNW = NT / 64;
   // One workgroup per image: latency bound.  When the stage pipeline runs it beside the chip-filling crop kernel, the
   // crop's waves on this CU must not take its issue slots (they cost the crop 1/16 of its CUs, this kernel 40 %).
   __builtin_amdgcn_s_setprio(3);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // wave areas first (float4 alignment), then the 4-byte and 2-byte arrays
+  // wave areas / small-V arrays first (float4 alignment), then the 4-byte and 2-byte arrays
   unsigned char *wave_area = smem;
-  uint32_t *key = reinterpret_cast<uint32_t *>(smem + (size_t)nms_waves * dec_wave_bytes(Rpc4));  // [Vcap] ascending = score desc
+  uint32_t *key = reinterpret_cast<uint32_t *>(smem + dec_area_bytes(Rpc4, nms_waves, capV));  // [Vcap] ascending = score desc
   uint32_t *pk = key + Vcap;                                  // [Vcap] (class << 24) | roi
   uint32_t *hist = pk + Vcap;                                 // [kNW*256]
   int *wsum = reinterpret_cast<int *>(hist + kNW * 256);      // [32]
@@ -125,7 +134,8 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
   }
   __syncthreads();
   FRCNN_STAMP(21);
-  // A2: the R*L (roi, class) elements in flat order, a contiguous run per thread: count, scan, place
+  // A2: the R*L (roi, class) elements in flat order, a contiguous run per thread: count (per thread for the compaction, per
+  // class for the segments), scan, place
   const int RL = R * L;
   const int E = (RL + kNT - 1) / kNT;
   const int e0 = tid * E;
@@ -135,7 +145,10 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
     int r = (e0 < RL) ? e0 / L : 0;
     int l = e0 - r * L;
     for (int e = e0; e < e1; ++e) {
-      cnt += (roi_fg[r] != 0) && (sprob[e] > p.score_thr);
+      if ((roi_fg[r] != 0) && (sprob[e] > p.score_thr)) {
+        ++cnt;
+        atomicAdd(&ccount[l], 1);
+      }
       if (++l == L) {
         l = 0;
         ++r;
@@ -144,61 +157,7 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
   }
   int V;
   int pos = block_excl_scan<NT>(cnt, wsum, V);
-  if (cnt) {
-    int r = e0 / L;
-    int l = e0 - r * L;
-    for (int e = e0; e < e1; ++e) {
-      const float v = sprob[e];
-      if (roi_fg[r] != 0 && v > p.score_thr && pos < Vcap) {
-        key[pos] = ~f_order_key(v);
-        pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
-        atomicAdd(&ccount[l], 1);
-        ++pos;
-      }
-      if (++l == L) {
-        l = 0;
-        ++r;
-      }
-    }
-  }
-  if (V > Vcap) V = Vcap;  // cannot happen: Vcap >= R*L
-  __syncthreads();
-  FRCNN_STAMP(22);
-
-  // ---- B. order by (class asc, score desc, roi asc) -----------------------------------------------------
-  int soff = 0;  // offset of the sorted order inside perm
-  if (V <= kNT) {
-    // rank by counting, all NT threads: `parts` threads share one candidate, each scanning a slice of the others
-    // (LDS broadcast reads), partial ranks summed in LDS.  V is a few hundred: one thread per candidate left 3/4 of the
-    // workgroup idle for V dependent LDS round trips.
-    const int Vp = (V + 63) & ~63;
-    const int parts = Vp > 0 ? kNT / Vp : 1;  // >= 1
-    uint32_t *racc = hist;                     // [V] partial-rank accumulators
-    for (int i = tid; i < V; i += kNT) racc[i] = 0u;
-    __syncthreads();
-    const int part = Vp > 0 ? tid / Vp : 0;
-    const int elem = tid - part * Vp;
-    if (part < parts && elem < V) {
-      const uint64_t mine = ((uint64_t)(pk[elem] >> 24) << 32) | key[elem];
-      const int j0 = (int)((long long)V * part / parts), j1 = (int)((long long)V * (part + 1) / parts);
-      int rank = 0;
-      for (int j = j0; j < j1; ++j) {
-        const uint64_t other = ((uint64_t)(pk[j] >> 24) << 32) | key[j];
-        rank += (other < mine) || (other == mine && j < elem);
-      }
-      atomicAdd(&racc[elem], (uint32_t)rank);
-    }
-    __syncthreads();
-    if (tid < V) perm[racc[tid]] = (uint16_t)tid;
-    __syncthreads();
-  } else {
-    for (int i = tid; i < V; i += kNT) perm[i] = (uint16_t)i;  // (published by the sort's first barrier)
-    soff = block_sort_digits<NT>(
-        [&](int slot, int pass) -> uint32_t { return pass < 4 ? (key[slot] >> (8 * pass)) : (pk[slot] >> 24); }, 5, perm,
-        Vcap, V, hist, wsum);
-  }
-  const uint16_t *sperm = perm + soff;
-  // class segment starts: exclusive prefix of ccount (wave 0, 4 classes per lane)
+  // class segment starts: exclusive prefix of ccount (wave 0, 4 classes per lane; the adds above are behind the scan's barriers)
   if (w == 0) {
     const int c0 = ccount[4 * lane], c1 = ccount[4 * lane + 1], c2 = ccount[4 * lane + 2], c3 = ccount[4 * lane + 3];
     int inc = c0 + c1 + c2 + c3;
@@ -210,6 +169,229 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves) {
     cstart[4 * lane + 2] = ex + c0 + c1;
     cstart[4 * lane + 3] = ex + c0 + c1 + c2;
   }
+  if (V > Vcap) V = Vcap;  // cannot happen: Vcap >= R*L
+  const bool small = V <= capV;  // workgroup-uniform
+  // the slots grouped by class, arrival order inside a class (small-V schedule only); hist holds 4 * NT words, of which the
+  // rank accumulators and the merge keys of that schedule take the first 3 * capV
+  uint16_t *cseg = reinterpret_cast<uint16_t *>(hist + 3 * capV);  // [capV]
+  int *cfill = kcount;  // [L] segment fill counters (the NMS overwrites every class's entry)
+  __syncthreads();
+  if (cnt) {
+    int r = e0 / L;
+    int l = e0 - r * L;
+    for (int e = e0; e < e1; ++e) {
+      const float v = sprob[e];
+      if (roi_fg[r] != 0 && v > p.score_thr && pos < Vcap) {
+        key[pos] = ~f_order_key(v);
+        pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
+        if (small) cseg[cstart[l] + atomicAdd(&cfill[l], 1)] = (uint16_t)pos;
+        ++pos;
+      }
+      if (++l == L) {
+        l = 0;
+        ++r;
+      }
+    }
+  }
+  __syncthreads();
+  FRCNN_STAMP(22);
+
+  if (small) {
+    // ================= small-V schedule (V <= NT: the reference's softmax inputs give at most one candidate per RoI) =====
+    float4 *snorm = reinterpret_cast<float4 *>(wave_area);     // [capV] corner-normalised boxes in (class, score, roi) order
+    float4 *sorig = snorm + capV;                              // [capV] the decoded boxes as they are written out
+    float2 *saf = reinterpret_cast<float2 *>(sorig + capV);    // [capV] (area, flags)
+    uint16_t *kq = reinterpret_cast<uint16_t *>(saf + capV);   // [capV] class c's kept entries: sorted positions, at cstart[c] ..
+    uint16_t *sslot = kq + capV;                               // [capV] slot of a sorted position
+    uint32_t *racc = hist;                                     // [capV] rank accumulators (both rankings)
+    unsigned long long *kcomp = reinterpret_cast<unsigned long long *>(hist + capV);  // [capV] (key, class, selection order)
+    // ---- B. rank inside the class: only the m candidates of one class are compared (a few dozen), `parts` threads share
+    // a candidate when V is small ----------------------------------------------------------------------------------
+    const int Vp = (V + 63) & ~63;
+    const int parts = Vp > 0 ? kNT / Vp : 1;  // >= 1 (V <= capV <= NT)
+    const int part = Vp > 0 ? tid / Vp : 0;
+    const int q = tid - part * Vp;  // position in cseg
+    for (int i = tid; i < V; i += kNT) racc[i] = 0u;
+    __syncthreads();
+    int slot = 0, cls = 0, s0 = 0;
+    if (part < parts && q < V) {
+      slot = (int)cseg[q];
+      cls = (int)(pk[slot] >> 24);
+      s0 = cstart[cls];
+      const int m = ccount[cls];
+      const uint32_t mykey = key[slot];
+      const int j0 = s0 + (int)((long long)m * part / parts), j1 = s0 + (int)((long long)m * (part + 1) / parts);
+      int rank = 0;
+      for (int j = j0; j < j1; ++j) {
+        const int o = (int)cseg[j];
+        const uint32_t ok = key[o];
+        rank += (ok < mykey) || (ok == mykey && o < slot);  // slots ascend with the roi inside a class
+      }
+      if (rank) atomicAdd(&racc[q], (uint32_t)rank);
+    }
+    __syncthreads();
+    // ---- decode every candidate once, into its sorted position -----------------------------------------------------
+    if (part == 0 && q < V) {
+      const int qq = s0 + (int)racc[q];
+      racc[q] = 0u;  // (own entry; reused by the cross-class ranking)
+      const float4 box = box_of((int)(pk[slot] & 0xFFFFFFu), cls);
+      const NBox nb = normalise_box(box);
+      snorm[qq] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
+      sorig[qq] = box;
+      saf[qq] = make_float2(nb.area, __int_as_float(box_flags(box, nb)));
+      sslot[qq] = (uint16_t)slot;
+      kcomp[qq] = ~0ull;  // "not kept"
+    }
+    __syncthreads();
+    FRCNN_STAMP(23);
+    // ---- C. per-class greedy NMS, the classes dealt to all waves, boxes from LDS ---------------------------------------
+    for (int c = w; c < L; c += kNW) {
+      const int cs = cstart[c];
+      const int m = ccount[c];
+      const int Rk = (p.Rpc < m) ? p.Rpc : m;
+      int nk = 0;
+      for (int base = 0; base < m && nk < Rk; base += 64) {
+        const int nc = (m - base < 64) ? (m - base) : 64;
+        const int myq = cs + base + ((lane < nc) ? lane : 0);
+        const PBox me = load_pbox(snorm, saf, myq);
+        // a. against the kept list of this class
+        bool d = false;
+        for (int k0 = 0; k0 < nk; k0 += 4) {
+          PBox kb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) kb[u] = load_pbox(snorm, saf, (int)kq[cs + ((k0 + u < nk) ? (k0 + u) : (nk - 1))]);
+          bool irr = false, dd = false;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], p.iou, irr);
+          if (__builtin_expect(ballot64(irr || p.iou.slow_only) != 0ull, 0)) {
+            dd = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), p.iou.thr);
+          }
+          d = d | dd;
+          if (ballot64(!(d || (lane >= nc))) == 0ull) break;
+        }
+        // b. intra-tile mask: row i suppresses column lane (i < lane)
+        unsigned long long own = 0ull;
+        for (int i0 = 0; i0 < nc; i0 += 4) {
+          PBox rb[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rb[u] = load_pbox(snorm, saf, cs + base + ((i0 + u < nc) ? (i0 + u) : (nc - 1)));
+          bool irr = false;
+          bool bit[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, p.iou, irr);
+          if (__builtin_expect(ballot64(irr || p.iou.slow_only) != 0ull, 0)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), p.iou.thr);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned long long word = ballot64(bit[u] & (i0 + u < lane) & (lane < nc));
+            if (lane == i0 + u) own = word;
+          }
+        }
+        // c. greedy resolve (scalar), rows that suppress nothing are accepted in bulk
+        const unsigned long long rem0 = ballot64(d);
+        const unsigned long long nz = ballot64(own != 0ull);
+        const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
+        unsigned long long rem = uniform64(rem0);
+        unsigned long long alive = uniform64(~rem & valid);
+        unsigned long long keptbits = 0ull;
+        int cnt2 = nk;
+        while (alive != 0ull && cnt2 < Rk) {
+          const unsigned long long nza = alive & nz;
+          const int f = (nza != 0ull) ? (int)__builtin_ctzll(nza) : 64;
+          unsigned long long batch = (f >= 64) ? alive : (alive & ((1ull << f) - 1ull));
+          int nb = __popcll(batch);
+          if (nb > 0) {
+            if (cnt2 + nb > Rk) {
+              unsigned long long t = 0ull, bb = batch;
+              for (int k = cnt2; k < Rk; ++k) {
+                const unsigned long long low = bb & (0ull - bb);
+                t |= low;
+                bb ^= low;
+              }
+              batch = t;
+              nb = Rk - cnt2;
+            }
+            keptbits |= batch;
+            cnt2 += nb;
+            alive &= ~batch;
+            if (cnt2 >= Rk) break;
+          }
+          if (f < 64) {
+            keptbits |= (1ull << f);
+            ++cnt2;
+            rem |= readlane64(own, f);
+            alive &= ~(rem | keptbits);
+          }
+        }
+        if ((keptbits >> lane) & 1ull) {
+          const int kp = nk + __popcll(keptbits & lanemask_lt());
+          kq[cs + kp] = (uint16_t)myq;
+          // cross-class order: score desc (key asc), class asc, selection order
+          kcomp[cs + kp] = ((unsigned long long)key[sslot[myq]] << 32) | ((unsigned long long)c << 16) | (unsigned long long)kp;
+        }
+        nk += __popcll(keptbits);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (lane == 0) kcount[c] = nk;
+    }
+    __syncthreads();
+    FRCNN_STAMP(24);
+    // ---- D. cross-class merge: every kept entry counts the kept entries that precede it --------------------------------
+    if (w == 0) {
+      int t4 = kcount[4 * lane] + kcount[4 * lane + 1] + kcount[4 * lane + 2] + kcount[4 * lane + 3];
+      t4 = wave_incl_scan(t4);
+      if (lane == 63) misc[0] = t4;
+    }
+    unsigned long long mine = ~0ull;
+    if (part < parts && q < V) {
+      mine = kcomp[q];
+      if (mine != ~0ull) {
+        const int j0 = (int)((long long)V * part / parts), j1 = (int)((long long)V * (part + 1) / parts);
+        int rank = 0;
+        for (int j = j0; j < j1; ++j) rank += kcomp[j] < mine;  // (~0 = not kept: never smaller)
+        if (rank) atomicAdd(&racc[q], (uint32_t)rank);
+      }
+    }
+    __syncthreads();
+    FRCNN_STAMP(26);
+    const int total = misc[0];
+    const int nvalid = total < T ? total : T;
+    if (part == 0 && q < V && mine != ~0ull) {
+      const int rank = (int)racc[q];
+      if (rank < T) {
+        float4 o = sorig[kq[q]];
+        o.x = clip01(o.x);
+        o.y = clip01(o.y);
+        o.z = clip01(o.z);
+        o.w = clip01(o.w);
+        *reinterpret_cast<float4 *>(io.out_boxes + ((long long)b * T + rank) * 4) = o;
+        // the score back from its key: candidates are positive (prob > score_threshold >= 0)
+        if (io.out_scores) io.out_scores[(long long)b * T + rank] = u2f(~(uint32_t)(mine >> 32) & 0x7FFFFFFFu);
+        if (io.out_labels) io.out_labels[(long long)b * T + rank] = (float)(int)((mine >> 16) & 0xFFFFull);
+      }
+    }
+    for (int r = nvalid + tid; r < T; r += kNT) {
+      *reinterpret_cast<float4 *>(io.out_boxes + ((long long)b * T + r) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (io.out_scores) io.out_scores[(long long)b * T + r] = 0.0f;
+      if (io.out_labels) io.out_labels[(long long)b * T + r] = 0.0f;
+    }
+    if (tid == 0 && io.out_valid) io.out_valid[b] = nvalid;
+    FRCNN_STAMP(25);
+    return;
+  }
+
+  // ================= general schedule (more candidates than threads: un-normalised scores) ==============================
+  for (int i = tid; i < L; i += kNT) kcount[i] = 0;
+  // ---- B. order by (class asc, score desc, roi asc): stable LSD radix sort (4 score passes + 1 class pass) --------------
+  for (int i = tid; i < V; i += kNT) perm[i] = (uint16_t)i;  // (published by the sort's first barrier)
+  const int soff = block_sort_digits<NT>(
+      [&](int slot, int pass) -> uint32_t { return pass < 4 ? (key[slot] >> (8 * pass)) : (pk[slot] >> 24); }, 5, perm,
+      Vcap, V, hist, wsum);
+  const uint16_t *sperm = perm + soff;
   __syncthreads();
 
   FRCNN_STAMP(23);
@@ -456,9 +638,10 @@ int launch_decoder(const float *const *rois, const float *const *deltas, const f
   const int Vcap = (int)((rl + 7) & ~7ll);
   const int Rpc = max_total < R ? max_total : R;
   const int Rpc4 = (Rpc + 3) & ~3;
+  const int capV = Vcap < nt ? Vcap : nt;  // the small-V schedule takes images with up to this many candidates
   int nms_waves = small_footprint ? 4 : 8;
-  while (nms_waves > 1 && dec_lds_bytes(Vcap, Rpc4, nms_waves, nt) > 160 * 1024) nms_waves >>= 1;
-  const size_t lds = dec_lds_bytes(Vcap, Rpc4, nms_waves, nt);
+  while (nms_waves > 1 && dec_lds_bytes(Vcap, Rpc4, nms_waves, nt, capV) > 160 * 1024) nms_waves >>= 1;
+  const size_t lds = dec_lds_bytes(Vcap, Rpc4, nms_waves, nt, capV);
   if (lds > 160 * 1024) return FRCNN_OK;
   DecoderParams p;
   for (int g = 0; g < kDecoderGroups; ++g) {
@@ -487,7 +670,7 @@ int launch_decoder(const float *const *rois, const float *const *deltas, const f
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "decoder: hipFuncSetAttribute");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(B * groups)), dim3(nt), lds, stream, p, Vcap, Rpc4, nms_waves);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * groups)), dim3(nt), lds, stream, p, Vcap, Rpc4, nms_waves, capV);
   *handled = true;
   return check_launch("decoder (fused kernel)");
 }

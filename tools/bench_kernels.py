@@ -37,6 +37,25 @@ def timeit(fn, iters, warmup=5):
     return e0.elapsed_time(e1) / iters  # ms
 
 
+def timeit_raw(call, iters, warmup=5):
+    """`call()` enqueues one launch through the C ABI with every argument prepared beforehand (no allocation, no Python
+    layer): the per-call host cost (~5 us) stays below the kernels' run time, so back-to-back launches measure the GPU.
+    Returns (ms per launch by HIP events, host ms per enqueue)."""
+    import time
+    for _ in range(warmup):
+        call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        call()
+    host = (time.perf_counter() - t0) / iters * 1e3
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters, host
+
+
 SETS = 1  # --sets: input sets rotated through the iterations (1 = the same tensors every time, i.e. cache-warm inputs)
 
 
@@ -99,10 +118,18 @@ def case_roi_bbox(name, B, G, K, R, iters, mode="inference", delta_scale=1.0):
     """delta_scale < 1: clustered proposals (deltas shrunk, so the decoded boxes stay close to their anchors and overlap
     heavily): NMS consumes far more candidates before R boxes are kept -- the lazy kernel's slow regime."""
     hp, anchors, d, s, layer = rois_for(B, G, K, R, mode=mode, delta_scale=delta_scale)
-    ms = timeit(lambda: layer([d, s]), iters)
+    ms_layer = timeit(lambda: layer([d, s]), iters)
     N = anchors.shape[0]
-    return dict(case=name, kernel="proposal_kernel", ms=ms, bytes=B * (N * 4 + K * 16 + R * 16), B=B, N=N, K=K, R=R,
-                delta_scale=delta_scale, images_per_s=B / (ms * 1e-3))
+    _lib = pkg._lib
+    lib = _lib.lib()
+    out = torch.empty((B, R, 4), device=d.device)
+    ws = torch.empty(int(lib.frcnn_roi_bbox_workspace_bytes(B, N, K, R)) or 16, dtype=torch.uint8, device=d.device)
+    args = (_lib.ptr(d), _lib.ptr(s), _lib.ptr(layer.anchors), _lib.float4(hp["variances"]), B, N, K, R,
+            float(hp["nms_iou_threshold"]), _lib.ptr(out), None, None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(d.device))
+    ms, host = timeit_raw(lambda: lib.frcnn_roi_bbox(*args), iters)
+    assert torch.equal(out, layer([d, s]))
+    return dict(case=name, kernel="proposal_kernel", ms=ms, ms_python_layer=ms_layer, host_ms_per_call=host,
+                bytes=B * (N * 4 + K * 16 + R * 16), B=B, N=N, K=K, R=R, delta_scale=delta_scale, images_per_s=B / (ms * 1e-3))
 
 
 def case_roi_delta(name, B, R, M, L, iters):
@@ -125,8 +152,18 @@ def case_decoder(name, B, R, L, iters):
     hd, hpb = synth.head_outputs(0, B, R, L)
     rois, hd, hpb = (torch.as_tensor(a).cuda() for a in (rois, hd, hpb))
     layer = pkg.faster_rcnn.Decoder(hp["variances"], L)
-    ms = timeit(lambda: layer([rois, hd, hpb]), iters)
-    return dict(case=name, kernel="decoder (sort + nms + merge)", ms=ms, bytes=B * (R * 16 + R * L * 20 + 200 * 24), B=B, R=R, L=L,
+    ms_layer = timeit(lambda: layer([rois, hd, hpb]), iters)
+    _lib = pkg._lib
+    lib = _lib.lib()
+    T = layer.max_total_size
+    ob, ol, osc = (torch.empty(sh, device=rois.device) for sh in ((B, T, 4), (B, T), (B, T)))
+    ws = torch.empty(int(lib.frcnn_decoder_workspace_bytes(B, R, L, T)) or 16, dtype=torch.uint8, device=rois.device)
+    args = (_lib.ptr(rois), _lib.ptr(hd), _lib.ptr(hpb), _lib.float4(layer.variances), B, R, L, T, float(layer.score_threshold), 0.5,
+            _lib.ptr(ob), _lib.ptr(ol), _lib.ptr(osc), None, _lib.ptr(ws), ws.numel(), _lib.stream_ptr(rois.device))
+    ms, host = timeit_raw(lambda: lib.frcnn_decoder(*args), iters)
+    want = layer([rois, hd, hpb])
+    assert torch.equal(ob, want[0]) and torch.equal(osc, want[2])
+    return dict(case=name, kernel="decoder (sort + nms + merge)", ms=ms, ms_python_layer=ms_layer, host_ms_per_call=host, bytes=B * (R * 16 + R * L * 20 + 200 * 24), B=B, R=R, L=L,
                 images_per_s=B / (ms * 1e-3))
 
 
