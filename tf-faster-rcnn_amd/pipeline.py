@@ -24,6 +24,7 @@ Host cost per batch is three C-ABI calls and a handful of event operations: outp
 
 from __future__ import annotations
 
+import ctypes
 import os
 import time
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
@@ -202,6 +203,7 @@ class RoIPathPipeline:
         self._ws_prop = torch.empty(max(1, lib.frcnn_roi_bbox_workspace_bytes(B, N, self._K, R)), dtype=torch.uint8, device=dev)
         self._ws_dec = torch.empty(max(1, lib.frcnn_decoder_workspace_bytes(B, R, L, T)), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize(dev)
+        self._slot_tables = {}  # pointer tables of slot-owned tensors per group of slots (they only change with the shape)
         self._shape_key = key
 
     # -- one batch ------------------------------------------------------------------------------------
@@ -308,6 +310,16 @@ class RoIPathPipeline:
         B, H, W, C = fm0.shape
         ph, pw = self._pool
         tab = _lib.ptr_table
+        own = self._slot_tables.get(tuple(ks))
+        if own is None:
+            own = {name: tab([getattr(s, name) for s in slots]) for name in ("rois", "pooled", "boxes", "labels", "scores")}
+            if self.host_outputs:
+                own["copies"] = []  # arguments of frcnn_gather_copy_multi, at most 8 segments a launch
+                for i in range(0, n, 8):
+                    grp = slots[i:i + 8]
+                    own["copies"].append((tab([s.small for s in grp]), tab([s.h_small for s in grp]),
+                                          (ctypes.c_size_t * len(grp))(*[s.small.numel() * 4 for s in grp]), len(grp)))
+            self._slot_tables[tuple(ks)] = own
 
         for k in ks:
             if self.slots[k].wait_in:
@@ -315,7 +327,7 @@ class RoIPathPipeline:
         if "prop" not in self._skip:
             _lib.check(lib.frcnn_roi_bbox_multi(tab([s.inputs[0] for s in slots]), tab([s.inputs[1] for s in slots]),
                                                 self.roi_bbox.anchors.data_ptr(), self._var_prop, n, B, N, self._K, R,
-                                                self._thr, tab([s.rois for s in slots]), self._ws_prop.data_ptr(),
+                                                self._thr, own["rois"], self._ws_prop.data_ptr(),
                                                 self._ws_prop.numel(), q_prop))
         ev_rois = self._ev_rois[ks[0]]
         ev_rois.record(q_prop)
@@ -325,9 +337,8 @@ class RoIPathPipeline:
         if timing is not None:
             timing[0].record(q_pool)
         if "crop" not in self._skip:
-            _lib.check(lib.frcnn_crop_and_resize_multi(tab([s.pending[0] for s in slots]), tab([s.rois for s in slots]),
-                                                       tab([s.pooled for s in slots]), n, B, H, W, C, B * R, R, ph, pw, 0.0,
-                                                       q_pool))
+            _lib.check(lib.frcnn_crop_and_resize_multi(tab([s.pending[0] for s in slots]), own["rois"], own["pooled"],
+                                                       n, B, H, W, C, B * R, R, ph, pw, 0.0, q_pool))
         if timing is not None:
             timing[1].record(q_pool)
         outs = []
@@ -349,14 +360,16 @@ class RoIPathPipeline:
 
         ev_heads.wait(q_dec)
         if "dec" not in self._skip:
-            _lib.check(lib.frcnn_decoder_multi(tab([s.rois for s in slots]), tab([o[0] for o in outs]), tab([o[1] for o in outs]),
+            _lib.check(lib.frcnn_decoder_multi(own["rois"], tab([o[0] for o in outs]), tab([o[1] for o in outs]),
                                                self._var_dec, n, B, R, L, T, float(self.decoder.score_threshold), 0.5,
-                                               tab([s.boxes for s in slots]), tab([s.labels for s in slots]),
-                                               tab([s.scores for s in slots]), self._ws_dec.data_ptr(), self._ws_dec.numel(),
-                                               q_dec))
+                                               own["boxes"], own["labels"], own["scores"], self._ws_dec.data_ptr(),
+                                               self._ws_dec.numel(), q_dec))
+        if self.host_outputs:
+            # ONE copy kernel moves the group's small outputs into their pinned buffers (a copy-engine transfer here costs
+            # 18 % of the throughput)
+            for srcs, dsts, sizes, cnt in own["copies"]:
+                _lib.check(lib.frcnn_gather_copy_multi(srcs, dsts, sizes, cnt, q_dec))
         for s, (pred_deltas, pred_probs) in zip(slots, outs):
-            if self.host_outputs:  # a copy kernel into the pinned buffer (a copy-engine transfer here costs 18 % of the throughput)
-                _lib.check(lib.frcnn_gather_copy(s.small.data_ptr(), s.h_small.data_ptr(), s.small.numel() * 4, q_dec))
             s.done.record(q_dec)
             s.inputs = s.inputs + (pred_deltas, pred_probs)
             s.pending = None
