@@ -21,6 +21,7 @@ namespace frcnn {
 
 static const int kTNT = 1024;
 static const int kTNW = 16;
+static const int kMaxPosList = 1024;  // rpn_targets_kernel: selected positives listed in LDS (beyond that: encoded in place)
 
 // ascending-order key: smaller = better (larger signed int first)
 __device__ __forceinline__ uint32_t inv_key(int key) { return ~(((uint32_t)key) ^ 0x80000000u); }
@@ -51,9 +52,13 @@ struct NoMask {};
 // contract, but out-of-contract ones are honoured), the elements with key <= 0 are all unmasked and dropped by the caller
 // whatever their rank: the radix selection is skipped.  This is the usual case for the positives of target assignment
 // (a few dozen anchors above the IoU threshold against S = 128).
+// hist4k (optional, with kcache): 4096 uint32 of LDS.  When every key lies in [0, 4096) -- mask * (a random integer below
+// 10 * the sample count: the reference's own range, utils/train_utils.py:82-83) -- the rank-S key comes out of ONE counting
+// pass (a histogram over the key values and a block scan from the top) instead of the radix passes.
 template <class KeyF, class EmitF, class MaskF = NoMask>
 __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t *hist, int *misc, int *wsum,
-                                               EmitF emit, uint32_t *kcache = nullptr, MaskF maskf = MaskF()) {
+                                               EmitF emit, uint32_t *kcache = nullptr, MaskF maskf = MaskF(),
+                                               uint32_t *hist4k = nullptr) {
   constexpr bool kHasMask = !__is_same(MaskF, NoMask);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (S <= 0 || S >= N) {  // uniform: nobody / everybody has rank < S
@@ -70,14 +75,23 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
     __syncthreads();  // the cache may still be read by a previous selection
     int npos = 0, bad = 0;
     uint32_t orv = 0u, andv = 0xFFFFFFFFu;
-    for (int n = tid; n < N; n += kTNT) {
-      const int k = keyf(n);
-      const uint32_t ik = inv_key(k);
-      kcache[n] = ik;
-      orv |= ik;
-      andv &= ik;
-      npos += (k > 0);
-      if constexpr (kHasMask) bad |= (k <= 0) && maskf(n);
+    for (int n0 = tid; n0 < N; n0 += 4 * kTNT) {  // four elements' loads in flight (keyf usually reads global memory)
+      int k4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) k4[u] = (n0 + u * kTNT < N) ? keyf(n0 + u * kTNT) : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u * kTNT;
+        if (n < N) {
+          const int k = k4[u];
+          const uint32_t ik = inv_key(k);
+          kcache[n] = ik;
+          orv |= ik;
+          andv &= ik;
+          npos += (k > 0);
+          if constexpr (kHasMask) bad |= (k <= 0) && maskf(n);
+        }
+      }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -103,9 +117,49 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
     common = (uint32_t)misc[4];
     vary = common ^ (uint32_t)misc[5];
   }
+  FRCNN_STAMP(35);
   auto key_at = [&](int n) -> uint32_t { return kcache ? kcache[n] : inv_key(keyf(n)); };
   uint32_t prefix = 0;
   int need = S;
+  const bool counting = kcache && hist4k && (common >> 12) == 0x7FFFFu && (vary >> 12) == 0u;  // block-uniform
+  if (counting) {
+    // inv_key(k) = 0x7FFFF000 + (4095 - k) for k in [0, 4096): bin d = 4095 - k ascends as the key descends
+    for (int i = tid; i < 4096; i += kTNT) hist4k[i] = 0u;
+    __syncthreads();
+    for (int n = tid; n < N; n += kTNT) {
+      const uint32_t d = kcache[n] - 0x7FFFF000u;
+      if (d != 4095u) atomicAdd(&hist4k[d], 1u);  // key 0 (masked out, most of the row) is what is left over
+    }
+    __syncthreads();
+    static_assert(kTNT * 4 == 4096, "four bins per thread");
+    const uint32_t a0 = hist4k[4 * tid], a1 = hist4k[4 * tid + 1], a2 = hist4k[4 * tid + 2], a3 = hist4k[4 * tid + 3];
+    int total;
+    const int ex = block_excl_scan((int)(a0 + a1 + a2 + a3), wsum, total);  // keys above this thread's bins / positive keys
+    if (ex < S && S <= ex + (int)(a0 + a1 + a2 + a3)) {  // exactly one thread when S <= total
+      int cum = ex, d = 4 * tid;
+      if (cum + (int)a0 < S) {
+        cum += (int)a0;
+        ++d;
+        if (cum + (int)a1 < S) {
+          cum += (int)a1;
+          ++d;
+          if (cum + (int)a2 < S) {
+            cum += (int)a2;
+            ++d;
+          }
+        }
+      }
+      misc[0] = d;
+      misc[1] = S - cum;
+    }
+    if (tid == 0 && S > total) {  // the quota reaches into the zeros: they fill it in index order
+      misc[0] = 4095;
+      misc[1] = S - total;
+    }
+    __syncthreads();
+    prefix = 0x7FFFF000u + (uint32_t)misc[0];
+    need = misc[1];
+  } else
   for (int pass = 3; pass >= 0; --pass) {
     const int shift = pass * 8;
     if (((vary >> shift) & 255u) == 0u) {  // block-uniform: every key carries the same digit here
@@ -158,6 +212,7 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
   }
   const uint32_t T = prefix;
   const int need_eq = need;
+  FRCNN_STAMP(36);
   // index-ordered rank among the elements with key == T: every thread owns a contiguous run of elements, one block scan
   // of the per-run counts gives the rank of its first equal element
   const int E = (N + kTNT - 1) / kTNT;
@@ -167,6 +222,7 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
   for (int n = n0; n < n1; ++n) eq += (key_at(n) == T);
   int total_eq;
   int rank = block_excl_scan(eq, wsum, total_eq);
+  FRCNN_STAMP(37);
   for (int n = n0; n < n1; ++n) {
     const uint32_t k = key_at(n);
     const bool is_eq = (k == T);
@@ -192,7 +248,8 @@ __global__ __launch_bounds__(1024) void select_mask_kernel(const uint8_t *__rest
                  [&](int n, bool in) { o[n] = (uint8_t)((m[n] != 0) && in); });
 }
 
-// utils/train_utils.py:180-202, one image per workgroup.  LDS: three N-bit maps.
+// utils/train_utils.py:180-202, one image per workgroup.  LDS: five N-bit maps (forced / positive mask / "max IoU below
+// 0.3" / the two selections), optionally the selection keys (N words) and the 4096 counting bins.
 __global__ __launch_bounds__(1024) void rpn_targets_kernel(
     const float *__restrict__ anchors, const float *__restrict__ gt_boxes, const int *__restrict__ gt_labels,
     const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int N, int M,
@@ -204,15 +261,21 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   __shared__ int misc[8];
   __shared__ int wsum[kTNW];
   __shared__ int s_pos_count;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int words = (N + 31) >> 5;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int words = ((N + 63) >> 6) << 1;  // whole 64-bit words: a wave's ballot is stored as one
   uint32_t *forced = maps;
   uint32_t *pos_sel = maps + words;
   uint32_t *neg_sel = maps + 2 * words;
-  uint32_t *kcache = cache_keys ? maps + 3 * words : nullptr;  // [N]
+  uint32_t *pos_msk = maps + 3 * words;  // max IoU > 0.7 or forced (:180-188)
+  uint32_t *low_msk = maps + 4 * words;  // max IoU < 0.3 (:193)
+  uint32_t *kcache = cache_keys ? maps + 5 * words : nullptr;  // [N]
+  uint32_t *hist4k = cache_keys ? kcache + N : nullptr;        // [4096]
+  int *krn = cache_keys ? reinterpret_cast<int *>(hist4k + 4096) : nullptr;  // [N] the negatives' random integers
+  int *plist = cache_keys ? krn + N : nullptr;                 // [kMaxPosList] the selected positives
   const float *miou = max_iou + (long long)b * N;
   const int *rp = rnd_pos ? rnd_pos + (long long)b * N : nullptr;
   const int *rn = rnd_neg ? rnd_neg + (long long)b * N : nullptr;
+  auto bit = [](const uint32_t *map, int n) -> bool { return (map[n >> 5] >> (n & 31)) & 1u; };
 
   FRCNN_STAMP(30);
   for (int i = tid; i < 3 * words; i += kTNT) maps[i] = 0u;
@@ -226,21 +289,62 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
     }
   }
   __syncthreads();
+  // The two masks as bit maps, the per-anchor inputs read ONCE (coalesced, twelve loads per thread in flight): with the
+  // key cache the positives' raw keys (mask * random integer) and the negatives' random integers go to LDS here, and the
+  // selections' key and emit functions only touch LDS.
+  {
+    const int n_up = (N + 63) & ~63;  // whole waves (uniform per wave) for the ballots
+    for (int n0 = tid; n0 < n_up; n0 += 4 * kTNT) {
+      float mi[4];
+      int rpv[4], rnv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u * kTNT;
+        mi[u] = (n < N) ? miou[n] : 0.5f;
+        rpv[u] = rnv[u] = 0;
+        if (kcache && n < N) {
+          rpv[u] = rp ? rp[n] : draw_int(seed, 0u, b, n, 10 * total_pos);
+          rnv[u] = rn ? rn[n] : draw_int(seed, 1u, b, n, 10 * (total_pos + total_neg));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int n = n0 + u * kTNT;
+        if (n - lane < n_up) {  // wave-uniform
+          const bool live = n < N;
+          const bool pmb = live && ((mi[u] > 0.7f) || bit(forced, n));
+          const unsigned long long pm = ballot64(pmb);
+          const unsigned long long lm = ballot64(live && (mi[u] < 0.3f));
+          if (kcache && live) {
+            kcache[n] = (uint32_t)((pmb ? 1 : 0) * rpv[u]);  // the raw key; select_largest turns it into its sort key
+            krn[n] = rnv[u];
+          }
+          if (lane == 0) {
+            pos_msk[n >> 5] = (uint32_t)pm;
+            pos_msk[(n >> 5) + 1] = (uint32_t)(pm >> 32);
+            low_msk[n >> 5] = (uint32_t)lm;
+            low_msk[(n >> 5) + 1] = (uint32_t)(lm >> 32);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
 
   FRCNN_STAMP(31);
   // :180,:188-189 positives, sub-sampled to total_pos
   auto pos_key = [&](int n) -> int {
-    const bool msk = (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u);
+    if (kcache) return (int)kcache[n];  // (each thread reads the slot it then overwrites)
     const int r = rp ? rp[n] : draw_int(seed, 0u, b, n, 10 * total_pos);
-    return (msk ? 1 : 0) * r;
+    return (bit(pos_msk, n) ? 1 : 0) * r;
   };
   select_largest(pos_key, N, total_pos, hist, misc, wsum, [&](int n, bool in) {
-    const bool msk = (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u);
-    if (msk && in) {
+    if (in && bit(pos_msk, n)) {
       atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
-      atomicAdd(&s_pos_count, 1);
+      const int at = atomicAdd(&s_pos_count, 1);
+      if (plist && at < kMaxPosList) plist[at] = n;
     }
-  }, kcache, [&](int n) -> bool { return (miou[n] > 0.7f) || ((forced[n >> 5] >> (n & 31)) & 1u); });
+  }, kcache, [&](int n) -> bool { return bit(pos_msk, n); }, hist4k);
   __syncthreads();
   FRCNN_STAMP(32);
   // :190-191
@@ -248,29 +352,24 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
 
   // :193-194 negatives, sub-sampled to neg_count
   auto neg_key = [&](int n) -> int {
-    const bool msk = (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u);
-    const int r = rn ? rn[n] : draw_int(seed, 1u, b, n, 10 * (total_pos + total_neg));
+    const bool msk = bit(low_msk, n) && !bit(pos_sel, n);
+    const int r = krn ? krn[n] : (rn ? rn[n] : draw_int(seed, 1u, b, n, 10 * (total_pos + total_neg)));
     return (msk ? 1 : 0) * r;
   };
   select_largest(neg_key, N, neg_count, hist, misc, wsum, [&](int n, bool in) {
-    const bool msk = (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u);
-    if (msk && in) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
-  }, kcache, [&](int n) -> bool { return (miou[n] < 0.3f) && !((pos_sel[n >> 5] >> (n & 31)) & 1u); });
+    if (in && bit(low_msk, n) && !bit(pos_sel, n)) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
+  }, kcache, [&](int n) -> bool { return bit(low_msk, n) && !bit(pos_sel, n); }, hist4k);
   __syncthreads();
 
   FRCNN_STAMP(33);
-  // :195-200 labels and regression targets
-  for (int n = tid; n < N; n += kTNT) {
-    const bool pos = (pos_sel[n >> 5] >> (n & 31)) & 1u;
-    const bool neg = (neg_sel[n >> 5] >> (n & 31)) & 1u;
-    const float pl = pos ? 1.0f : -1.0f;
-    const float nl = neg ? 1.0f : 0.0f;
-    out_labels[(long long)b * N + n] = pl + nl;
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pos && M > 0) {
-      const int m = argmax_row[(long long)b * N + n];
-      g = *reinterpret_cast<const float4 *>(gt_boxes + ((long long)b * M + m) * 4);
-    }
+  // :195-200 labels and regression targets.  An anchor that is not positive is paired with the all-zero gt row, for which
+  // get_deltas_from_bboxes yields exactly (0, 0, 0, 0) whatever the anchor (bbox_utils.py:121-135: gt width and height
+  // are 0, so every tf.where takes its zeros branch): only the positives read their anchor and gt box and go through
+  // the encoder; the rest of the (N,4) rows is a streamed constant, 0 / variance.
+  const float4 zero_d = make_float4(0.0f / v0, 0.0f / v1, 0.0f / v2, 0.0f / v3);
+  auto encode_row = [&](int n) {
+    const int m = argmax_row[(long long)b * N + n];
+    const float4 g = *reinterpret_cast<const float4 *>(gt_boxes + ((long long)b * M + m) * 4);
     const float4 a = *reinterpret_cast<const float4 *>(anchors + (long long)n * 4);
     float4 d = encode_box(a, g);
     d.x = d.x / v0;
@@ -278,7 +377,25 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
     d.z = d.z / v2;
     d.w = d.w / v3;
     *reinterpret_cast<float4 *>(out_deltas + ((long long)b * N + n) * 4) = d;
+  };
+  // with the list of positives the streamed pass has no loads and no divergent work; the positives (at most total_pos)
+  // are encoded by one thread each afterwards
+  const int npos_sel = s_pos_count;
+  const bool listed = plist && npos_sel <= kMaxPosList;  // block-uniform
+  for (int n = tid; n < N; n += kTNT) {
+    const bool pos = bit(pos_sel, n);
+    const bool neg = bit(neg_sel, n);
+    const float pl = pos ? 1.0f : -1.0f;
+    const float nl = neg ? 1.0f : 0.0f;
+    out_labels[(long long)b * N + n] = pl + nl;
+    if (pos && M > 0) {
+      if (!listed) encode_row(n);
+    } else {
+      *reinterpret_cast<float4 *>(out_deltas + ((long long)b * N + n) * 4) = zero_d;
+    }
   }
+  if (listed && M > 0)
+    for (int i = tid; i < npos_sel; i += kTNT) encode_row(plist[i]);
   FRCNN_STAMP(34);
 }
 
@@ -466,10 +583,12 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
   const size_t keys_bytes = frcnn_iou_reduce_workspace_bytes(B, N, M);
   int rc = frcnn_iou_map_reduce(anchors, 0, gt_boxes, B, N, M, max_iou, argmax_row, argmax_col, keys, keys_bytes, stream);
   if (rc) return rc;
-  const int words = (N + 31) >> 5;
-  size_t lds = (size_t)3 * words * 4;
-  const int cache_keys = (lds + (size_t)N * 4 <= 128 * 1024) ? 1 : 0;  // the selections' keys, once instead of per pass
-  if (cache_keys) lds += (size_t)N * 4;
+  const int words = ((N + 63) >> 6) << 1;
+  size_t lds = (size_t)5 * words * 4;
+  // the selections' keys, the negatives' random integers, the counting bins and the list of positives in LDS when they fit
+  const size_t cache_bytes = (size_t)N * 8 + 4096 * 4 + (size_t)kMaxPosList * 4;
+  const int cache_keys = (lds + cache_bytes <= 128 * 1024) ? 1 : 0;
+  if (cache_keys) lds += cache_bytes;
   auto kern = rpn_targets_kernel;
   if (lds > 48 * 1024) {
     rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "rpn_targets: hipFuncSetAttribute");
