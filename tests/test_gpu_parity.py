@@ -643,6 +643,33 @@ def test_rpn_targets_selection_regimes(pkg, total_pos, total_neg, bad_ints):
     assert_bits(got_d, want_d, "rpn deltas")
 
 
+@pytest.mark.parametrize("int_range", ["ties_1_3", "below_4096", "straddle_4096", "wide", "with_zero_and_negative"])
+@pytest.mark.parametrize("total_pos,total_neg", [(16, 40), (128, 128), (700, 900)])
+def test_rpn_targets_counting_selection(pkg, int_range, total_pos, total_neg):
+    """The selections of rpn_targets_kernel count over the 4096 key values when every key lies in [0, 4096) and fall
+    back to the radix passes otherwise: random integers with heavy ties, at the top of the range, straddling it, far
+    beyond it, and with zeros / negatives on masked anchors; quotas below, around and above the number of candidates."""
+    B, G, M = 3, 16, 20
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, total_pos_bboxes=total_pos, total_neg_bboxes=total_neg)
+    anchors = oracle.generate_anchors(hp)
+    N = anchors.shape[0]
+    gt, labels = synth.gt_boxes(21, B, M)
+    gt[:, :6] = anchors[[50, 400, 900, 1300, 1700, 2100]]  # exact anchor hits: positives with IoU 1 and their neighbours
+    labels[:, :6] = 2
+    rng = np.random.default_rng(5)
+    lo, hi = {"ties_1_3": (1, 4), "below_4096": (3000, 4096), "straddle_4096": (4000, 4200), "wide": (1, 2 ** 30),
+              "with_zero_and_negative": (-3, 50)}[int_range]
+    rp = rng.integers(lo, hi, (B, N)).astype(np.int32)
+    rn = rng.integers(lo, hi, (B, N)).astype(np.int32)
+    got_d, got_l = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp,
+                                                                random_masks=(dev(rp), dev(rn)))
+    want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
+    assert (want_l == 1).any() and (want_l == 0).any()
+    assert_bits(got_l, want_l, f"rpn labels ({int_range})")
+    assert_bits(got_d, want_d, f"rpn deltas ({int_range})")
+
+
 # ------------------------------------------------------------------------------------------------
 # RoIDelta (second-stage training targets)
 # ------------------------------------------------------------------------------------------------

@@ -400,7 +400,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
 }
 
 // models/faster_rcnn.py:218-234 (RoIDelta.call after the IoU reductions), one image per workgroup.
-// LDS: two R-bit maps, then the per-RoI encoded delta (float4), label (int) and selection key (uint32).
+// LDS: two R-bit maps, then the per-RoI encoded delta (float4), label (int), selection key (uint32) and the 4096 counting bins.
 __global__ __launch_bounds__(1024) void roi_delta_kernel(
     const float *__restrict__ rois, const float *__restrict__ gt_boxes, const int *__restrict__ gt_labels,
     const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int R, int M, int L,
@@ -418,6 +418,7 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
   float4 *s_delta = reinterpret_cast<float4 *>(maps + words4);  // [R]
   int *s_label = reinterpret_cast<int *>(s_delta + R);           // [R]
   uint32_t *kcache = reinterpret_cast<uint32_t *>(s_label + R);  // [R] selection keys
+  uint32_t *hist4k = kcache + R;                                 // [4096] counting bins
   const float *miou = max_iou + (long long)b * R;
   const int *rp = rnd_pos ? rnd_pos + (long long)b * R : nullptr;
   const int *rn = rnd_neg ? rnd_neg + (long long)b * R : nullptr;
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
       [&](int n, bool in) {
         if ((miou[n] > 0.5f) && in) atomicOr(&pos_sel[n >> 5], 1u << (n & 31));
       },
-      kcache);
+      kcache, NoMask(), hist4k);
   // :220-221 negatives: 0.1 < max IoU < 0.5, sub-sampled to total_neg
   select_largest(
       [&](int n) -> int {
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
       [&](int n, bool in) {
         if ((miou[n] < 0.5f) && (miou[n] > 0.1f) && in) atomicOr(&neg_sel[n >> 5], 1u << (n & 31));
       },
-      kcache);
+      kcache, NoMask(), hist4k);
   __syncthreads();
 
   // :222-230 per RoI: gathered gt box / label, encoded delta / variances
@@ -648,7 +649,7 @@ int frcnn_roi_delta(const float *rois, const float *gt_boxes, const int32_t *gt_
   int rc = frcnn_iou_map_reduce(rois, 1, gt_boxes, B, R, M, max_iou, argmax_row, nullptr, nullptr, 0, stream);
   if (rc) return rc;
   const int words = (R + 31) >> 5;
-  const size_t lds = (size_t)((2 * words + 3) & ~3) * 4 + (size_t)R * 24;
+  const size_t lds = (size_t)((2 * words + 3) & ~3) * 4 + (size_t)R * 24 + 4096 * 4;
   auto kern = roi_delta_kernel;
   if (lds > 48 * 1024) {
     rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds, "roi_delta: hipFuncSetAttribute");
