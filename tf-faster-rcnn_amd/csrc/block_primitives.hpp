@@ -301,6 +301,108 @@ __device__ __forceinline__ int block_sort_digits(DigitF digit, int npass, uint16
   return (npass & 1) ? stride : 0;
 }
 
+// Bucket sort of V slot numbers by (keys[slot], slot) ascending: 8 * NT buckets linear in the key over [lowest, highest
+// key] (16-bit counters, two to an LDS word), one LDS add per slot that also hands back its place inside the bucket, a
+// scan, the placement, and an insertion sort inside every bucket (the slot number as second key is what a stable sort of
+// index-ordered slots would give).  Seven barriers for any V, against four LSD passes of six.  fp32 score keys are
+// log-spaced across binades and linear inside one, so uniform scores put half the slots into 1/13 of the buckets: hence
+// the many buckets.  Pays when the keys spread, not when they cluster: returns false -- perm undefined -- when a bucket
+// holds more than 48 slots, and the caller sorts by radix instead.
+// perm: [V] out; place: [V] scratch; hist: 4 * NT uint32; wsum: NT / 64 ints; misc: >= 10 ints (uses [6], [7], [9]).  V < 65536.
+template <int NT = kNT>
+__device__ __forceinline__ bool block_bucket_sort_perm(const uint32_t *keys, uint16_t *perm, uint16_t *place, int V,
+                                                       uint32_t *hist, int *wsum, int *misc) {
+  constexpr int NBK = 8 * NT;
+  uint16_t *start = reinterpret_cast<uint16_t *>(hist);  // [NBK] counters, then bucket starts
+  const int tid = threadIdx.x;
+  __syncthreads();  // the caller's keys; hist / misc may still be read by what came before
+  if (tid == 0) {
+    misc[6] = -1;  // lowest key (unsigned min)
+    misc[7] = 0;   // highest key
+    misc[9] = 0;   // overflow
+  }
+  for (int i = tid; i < NBK / 2; i += NT) hist[i] = 0u;
+  __syncthreads();
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  for (int j = tid; j < V; j += NT) {
+    const uint32_t k = keys[j];
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const uint32_t ol = (uint32_t)__shfl_xor((int)lo, off, 64), oh = (uint32_t)__shfl_xor((int)hi, off, 64);
+    lo = ol < lo ? ol : lo;
+    hi = oh > hi ? oh : hi;
+  }
+  if ((tid & 63) == 0) {
+    atomicMin(reinterpret_cast<uint32_t *>(&misc[6]), lo);
+    atomicMax(reinterpret_cast<uint32_t *>(&misc[7]), hi);
+  }
+  __syncthreads();
+  const uint32_t kmin = (uint32_t)misc[6];
+  const float scale = (float)NBK / ((float)((uint32_t)misc[7] - kmin) + 1.0f);
+  auto bucket_of = [&](uint32_t k) -> int {
+    const int bkt = (int)((float)(k - kmin) * scale);  // monotone in k
+    return bkt < NBK - 1 ? bkt : NBK - 1;
+  };
+  for (int j = tid; j < V; j += NT) {
+    const int bkt = bucket_of(keys[j]);
+    const uint32_t old = atomicAdd(&hist[bkt >> 1], (bkt & 1) ? 0x10000u : 1u);  // (V < 65536: the low half cannot carry)
+    place[j] = (uint16_t)((bkt & 1) ? (old >> 16) : (old & 0xFFFFu));
+  }
+  __syncthreads();
+  {
+    uint32_t wds[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wds[u] = hist[4 * tid + u];
+    uint32_t sum = 0, big = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t c0 = wds[u] & 0xFFFFu, c1 = wds[u] >> 16;
+      sum += c0 + c1;
+      big = (c0 > big) ? c0 : big;
+      big = (c1 > big) ? c1 : big;
+    }
+    int total;
+    uint32_t run = (uint32_t)block_excl_scan<NT>((int)sum, wsum, total);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t c0 = wds[u] & 0xFFFFu, c1 = wds[u] >> 16;
+      hist[4 * tid + u] = run | ((run + c0) << 16);  // the two buckets' starts (< 65536)
+      run += c0 + c1;
+    }
+    if (big > 48u) misc[9] = 1;
+  }
+  __syncthreads();
+  if (misc[9]) return false;  // block-uniform
+  for (int j = tid; j < V; j += NT) perm[start[bucket_of(keys[j])] + place[j]] = (uint16_t)j;
+  __syncthreads();
+  {
+    uint32_t begin = start[8 * tid];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t end = (8 * tid + u + 1 < NBK) ? start[8 * tid + u + 1] : (uint32_t)V;
+      for (uint32_t a = begin + 1; a < end; ++a) {
+        const uint16_t sj = perm[a];
+        const uint32_t kj = keys[sj];
+        uint32_t c = a;
+        while (c > begin) {
+          const uint16_t sp = perm[c - 1];
+          const uint32_t kp = keys[sp];
+          if (!(kp > kj || (kp == kj && sp > sj))) break;
+          perm[c] = sp;
+          --c;
+        }
+        perm[c] = sj;
+      }
+      begin = end;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
 // The common case: 4 passes over 32-bit keys[slot]; the sorted order ends up in perm[0..V).
 __device__ __forceinline__ void block_sort_perm(const uint32_t *keys, uint16_t *perm, int stride, int V,
                                                 uint32_t *hist, int *wsum) {

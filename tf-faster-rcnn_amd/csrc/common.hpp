@@ -45,6 +45,7 @@ enum Knob {
   kKnobCropSort,         // FRCNN_CROP_SORT             0 = keep the RoIs in their given order there
   kKnobIouReduceSplit,   // FRCNN_IOU_REDUCE_SPLIT      0|1: the 64 boxes x 4 gt quarters form of the fused IoU reductions
   kKnobProposalExactSlices,  // FRCNN_PROPOSAL_EXACT_SLICES 1: the fused RoIBBox kernel cuts its slices by exact rank only
+  kKnobSortRadixOnly,    // FRCNN_SORT_RADIX_ONLY       1: sort_select_kernel orders its slots by the stable radix sort only
   kKnobCount
 };
 bool knob_set(Knob k);

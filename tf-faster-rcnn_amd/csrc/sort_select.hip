@@ -11,7 +11,8 @@
 //      histogram, global re-reads that stay in L2) finds the key of the K-th best element;
 //   2. the surviving elements are compacted into LDS in index order (blocked prefix scan), keyed by
 //      ~order_key(score) so that ascending key == descending score;
-//   3. a 4-pass, 8-bit, least-significant-digit radix sort permutes 16-bit slot numbers.  Stability
+//   3. the slots are ordered by (key, slot) with a bucket sort (block_primitives.hpp); when the keys cluster (a bucket
+//      overflows) a 4-pass, 8-bit, least-significant-digit radix sort permutes 16-bit slot numbers instead.  Stability
 //      is what yields "equal scores by ascending index": each wave owns a contiguous slice of the
 //      current order, counts its digits with LDS adds, the 256x16 counters are scanned digit-major /
 //      wave-minor, and each 64-element chunk ranks itself with an 8-ballot match of equal digits.
@@ -27,7 +28,7 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
                                                            float thr, int slots, int do_select,
                                                            int *__restrict__ sorted_idx,
                                                            float *__restrict__ sorted_val,
-                                                           int *__restrict__ counts, int out_stride) {
+                                                           int *__restrict__ counts, int out_stride, int no_bucket_sort) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                 // [slots]
   uint32_t *hist = keys + slots;                                       // [kNW*256]
@@ -117,8 +118,12 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
     if (V > slots) V = slots;  // defensive; cannot happen
   }
 
-  // ---- 3. stable LSD radix sort of the V slots --------------------------------------------------
-  block_sort_perm(keys, permA, slots, V, hist, wsum);
+  // ---- 3. order the V slots by (key, slot): bucket sort; stable LSD radix sort when the keys cluster ----------------
+  if (no_bucket_sort || !block_bucket_sort_perm(keys, permA, permA + slots, V, hist, wsum, misc)) {
+    __syncthreads();
+    for (int i = tid; i < V; i += kNT) permA[i] = (uint16_t)i;
+    block_sort_perm(keys, permA, slots, V, hist, wsum);
+  }
   const uint16_t *perm = permA;
 
   // ---- 4. emit ------------------------------------------------------------------------------------
@@ -161,6 +166,7 @@ int launch_sort_select(const ScoreSource &src, int B, int c, int n, int K, bool 
   const long long nseg = (long long)B * c;
   if (nseg >= (1ll << 31)) return set_error(FRCNN_EINVAL, "sort_select: too many segments");
   dim3 grid((unsigned)nseg), block(kNT);
+  const int no_bucket = knob(kKnobSortRadixOnly, 0) ? 1 : 0;  // FRCNN_SORT_RADIX_ONLY=1: the stable radix sort only
   if (idx16) {
     auto kern = sort_select_kernel<uint16_t>;
     if (lds > 48 * 1024) {
@@ -168,7 +174,7 @@ int launch_sort_select(const ScoreSource &src, int B, int c, int n, int K, bool 
       if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, src, c, n, keff, use_thr ? 1 : 0, thr, slots, do_select,
-                       sorted_idx, sorted_val, counts, out_stride);
+                       sorted_idx, sorted_val, counts, out_stride, no_bucket);
   } else {
     auto kern = sort_select_kernel<uint32_t>;
     if (lds > 48 * 1024) {
@@ -176,7 +182,7 @@ int launch_sort_select(const ScoreSource &src, int B, int c, int n, int K, bool 
       if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, grid, block, lds, stream, src, c, n, keff, use_thr ? 1 : 0, thr, slots, do_select,
-                       sorted_idx, sorted_val, counts, out_stride);
+                       sorted_idx, sorted_val, counts, out_stride, no_bucket);
   }
   return check_launch("sort_select");
 }
