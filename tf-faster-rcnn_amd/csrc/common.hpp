@@ -286,6 +286,16 @@ __device__ __forceinline__ bool nms_iou_gt(const NBox &i, const NBox &j, float t
   return iou > thr;
 }
 
+// ---- fused IoU reductions (iou_map.hip) ----------------------------------------------------------------
+// The per-gt argmax over the boxes is merged across workgroups as one 64-bit atomic max on (order key << 32 | ~index).
+// key 0: no box had an IoU above lowest() -> Eigen's ArgMax keeps its initial index 0.
+__host__ __device__ __forceinline__ int col_key_index(unsigned long long k) {
+  return (k == 0ull) ? 0 : (int)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull));
+}
+int iou_map_reduce_impl(const float *bboxes, int bboxes_batched, const float *gt_boxes, int B, int N, int M, float *max_iou,
+                        int32_t *argmax_row, int32_t *argmax_col, void *workspace, size_t workspace_bytes, hipStream_t stream,
+                        bool finalize);
+
 // ---- diagnostic stamps (only in builds with -DFRCNN_STAMPS; the shipped library has none) ---------
 #ifdef FRCNN_STAMPS
 extern __device__ long long g_stamps[256];

@@ -386,9 +386,7 @@ __global__ __launch_bounds__(256) void col_keys_to_index_kernel(const unsigned l
                                                                 int *__restrict__ argmax_col, int total) {
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
-  const unsigned long long k = keys[i];
-  // key 0: no box had an IoU above lowest() -> Eigen's ArgMax keeps its initial index 0.
-  argmax_col[i] = (k == 0ull) ? 0 : (int)(0xFFFFFFFFu - (uint32_t)(k & 0xFFFFFFFFull));
+  argmax_col[i] = col_key_index(keys[i]);
 }
 
 }  // namespace frcnn
@@ -439,6 +437,17 @@ size_t frcnn_iou_reduce_workspace_bytes(int B, int N, int M) {
 int frcnn_iou_map_reduce(const float *bboxes, int bboxes_batched, const float *gt_boxes, int B,
                          int N, int M, float *max_iou, int32_t *argmax_row, int32_t *argmax_col,
                          void *workspace, size_t workspace_bytes, frcnn_stream_t stream) {
+  return frcnn::iou_map_reduce_impl(bboxes, bboxes_batched, gt_boxes, B, N, M, max_iou, argmax_row, argmax_col, workspace,
+                                    workspace_bytes, (hipStream_t)stream, true);
+}
+
+}  // extern "C"
+
+// finalize = false: the per-gt argmax stays in its 64-bit key form in the workspace (B*M words, see col_key_index) and
+// argmax_col is not written -- frcnn_rpn_targets' kernel decodes the keys itself, one launch less.
+int frcnn::iou_map_reduce_impl(const float *bboxes, int bboxes_batched, const float *gt_boxes, int B, int N, int M,
+                               float *max_iou, int32_t *argmax_row, int32_t *argmax_col, void *workspace,
+                               size_t workspace_bytes, hipStream_t stream, bool finalize) {
   FRCNN_REQUIRE(bboxes && gt_boxes, "iou_map_reduce: null pointer");
   FRCNN_REQUIRE(B >= 0 && N >= 0 && M >= 0, "iou_map_reduce: negative shape");
   FRCNN_REQUIRE(aligned_to(bboxes, 16) && aligned_to(gt_boxes, 16), "iou_map_reduce: box pointers must be 16-byte aligned");
@@ -472,12 +481,10 @@ int frcnn_iou_map_reduce(const float *bboxes, int bboxes_batched, const float *g
     int rc = check_launch("iou_map_reduce");
     if (rc) return rc;
   }
-  if (keys) {
+  if (keys && finalize) {
     const int total = B * M;
     hipLaunchKernelGGL(col_keys_to_index_kernel, dim3((total + 255) / 256), dim3(256), 0, s, keys, argmax_col, total);
     return check_launch("iou_map_reduce finalize");
   }
   return FRCNN_OK;
 }
-
-}  // extern "C"

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
     const float *__restrict__ anchors, const float *__restrict__ gt_boxes, const int *__restrict__ gt_labels,
     const int *__restrict__ rnd_pos, const int *__restrict__ rnd_neg, unsigned long long seed, int N, int M,
     int total_pos, int total_neg, float v0, float v1, float v2, float v3, const float *__restrict__ max_iou,
-    const int *__restrict__ argmax_row, const int *__restrict__ argmax_col, float *__restrict__ out_deltas,
+    const int *__restrict__ argmax_row, const unsigned long long *__restrict__ col_keys, float *__restrict__ out_deltas,
     float *__restrict__ out_labels, int cache_keys) {
   extern __shared__ __attribute__((aligned(16))) uint32_t maps[];
   __shared__ uint32_t hist[256];
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   // :181-188 every valid gt forces its best anchor positive
   for (int m = tid; m < M; m += kTNT) {
     if (gt_labels[(long long)b * M + m] != -1) {
-      const int a = argmax_col[(long long)b * M + m];
+      const int a = col_key_index(col_keys[(long long)b * M + m]);  // the per-gt argmax, still in its merge-key form
       if (a >= 0 && a < N) atomicOr(&forced[a >> 5], 1u << (a & 31));
     }
   }
@@ -582,7 +582,8 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
   off += round_up((size_t)B * M * 4, 256);
   void *keys = p + off;
   const size_t keys_bytes = frcnn_iou_reduce_workspace_bytes(B, N, M);
-  int rc = frcnn_iou_map_reduce(anchors, 0, gt_boxes, B, N, M, max_iou, argmax_row, argmax_col, keys, keys_bytes, stream);
+  int rc = iou_map_reduce_impl(anchors, 0, gt_boxes, B, N, M, max_iou, argmax_row, argmax_col, keys, keys_bytes,
+                               (hipStream_t)stream, false);
   if (rc) return rc;
   const int words = ((N + 63) >> 6) << 1;
   size_t lds = (size_t)5 * words * 4;
@@ -597,7 +598,8 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(kTNT), lds, (hipStream_t)stream, anchors, gt_boxes, gt_labels, rnd_pos,
                      rnd_neg, (unsigned long long)seed, N, M, total_pos, total_neg, variances[0], variances[1],
-                     variances[2], variances[3], max_iou, argmax_row, argmax_col, out_deltas, out_labels, cache_keys);
+                     variances[2], variances[3], max_iou, argmax_row, reinterpret_cast<const unsigned long long *>(keys),
+                     out_deltas, out_labels, cache_keys);
   return check_launch("rpn_targets");
 }
 
