@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0,
 // One workgroup (1024 threads) per image.  LDS: removed[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
 __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
-  __shared__ unsigned long long s_kept;
-  __shared__ int s_nk;
+  __shared__ unsigned long long s_kept[2];  // double-buffered: wave 0 runs one block ahead of the waves that read them
+  __shared__ int s_nk[2];
   const int b = blockIdx.x;
   if (p.state[b * 4 + 1]) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -254,25 +254,29 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
       }
       if ((keptbits >> lane) & 1ull) kidx[nk + __popcll(keptbits & lanemask_lt())] = cb * 64 + lane;
       if (lane == 0) {
-        s_kept = keptbits;
-        s_nk = cnt;
+        s_kept[cb & 1] = keptbits;
+        s_nk[cb & 1] = cnt;
       }
     }
+    // ONE barrier per block: wave 0 folds this block's kept rows into the NEXT block (its own c1 = cb + 1) as soon as it has
+    // them, so it can resolve that block right after the barrier; the other waves fold into the blocks from cb + 2 on while
+    // it does -- those words are not read before a later barrier.  (Two waves may touch one word in the same interval: LDS
+    // atomics.)
     __syncthreads();
-    const unsigned long long kb = s_kept;
-    nk = s_nk;
+    const unsigned long long kb = s_kept[cb & 1];
+    nk = s_nk[cb & 1];
     // the columns of the later blocks that one of this block's kept rows suppresses: one AND and one ballot per block
     if (c1 < cb1) {
       const unsigned long long h1 = ballot64((f1 & kb) != 0ull);
-      if (lane == 0) removed[c1] |= h1;
+      if (lane == 0 && h1 != 0ull) atomicOr(&removed[c1], h1);
     }
     if (c2 < cb1) {
       const unsigned long long h2 = ballot64((f2 & kb) != 0ull);
-      if (lane == 0) removed[c2] |= h2;
+      if (lane == 0 && h2 != 0ull) atomicOr(&removed[c2], h2);
     }
     // kBandBlocks <= 32: c1 and c2 cover every later block of the band
-    __syncthreads();
   }
+  __syncthreads();  // the last block's folds and kept indices
 
   // (iii) finished (R boxes, or no candidates left): outputs; otherwise save the state for the next phase
   const bool finished = (nk >= R) || last_phase || (cb1 >= nb);
