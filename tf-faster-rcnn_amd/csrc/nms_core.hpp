@@ -205,282 +205,7 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// One chunk of nc (<= CH) candidates, in priority order, whose packed boxes (L.c_box, L.c_af), element indices (L.c_idx)
-// and initial dead words (L.dead[g]: candidates that fail the score threshold) are already in LDS -- written by this
-// workgroup, but not necessarily published yet: the function starts with a barrier.  L.c_* may point anywhere in LDS (a
-// slice decoded ahead of time); entries [nc, CH) are read but never influence a result.  nk = boxes kept so far; returns
-// the new count (<= R).  Must be called by all NT threads of the block.
-template <int NT, int CH>
-__device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr);
-
-// The same with the chunk loaded here: cand(j, box, ei, bad) fills candidate j's box (original corner order), element
-// index and "fails the score threshold" flag (called by threads j < nc).
-template <int NT, int CH, class CandF>
-__device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr, CandF cand) {
-  static_assert(NT >= CH && NT % CH == 0, "block must cover the chunk");
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid < CH) {
-    NBox nb;
-    nb.ymin = nb.xmin = nb.ymax = nb.xmax = nb.area = 0.0f;
-    int ei = -1, fl = 0;
-    bool bad = false;
-    if (tid < nc) {
-      float4 box;
-      cand(tid, box, ei, bad);
-      nb = normalise_box(box);
-      fl = box_flags(box, nb);
-    }
-    L.c_box[tid] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
-    L.c_area[tid] = nb.area;
-    L.c_flag[tid] = fl;
-    L.c_idx[tid] = ei;
-    const unsigned long long badw = ballot64(bad);  // candidates that fail the score threshold start dead
-    const unsigned long long regw = ballot64(fl == (kFlagArea | kFlagRegular));
-    if (lane == 0) {
-      L.dead[w] = badw;
-      L.reg[w] = regw;
-    }
-  }
-  return nms_chunk_resolve<NT, CH>(L, nc, nk, R, thr);
-}
-
-template <int NT, int CH>
-__device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr) {
-  static_assert(CH == 64 || CH == 128 || CH == 256, "chunk must be 1, 2 or 4 waves wide");
-  static_assert(NT >= CH && NT % CH == 0, "block must cover the chunk");
-  constexpr int G = CH / 64;
-  constexpr int NWV = NT / 64;
-  constexpr int NSL = NT / CH;                  // slices of the kept list handled in parallel
-  constexpr int TILES = G * (G + 1) / 2;        // upper-triangular 64x64 tiles
-  // row splits per tile: the largest power of two (<= 16) that keeps the work items within 4 per wave
-  constexpr int SPLIT = (TILES * 16 <= 4 * NWV) ? 16 : (TILES * 8 <= 4 * NWV) ? 8 : (TILES * 4 <= 4 * NWV) ? 4
-                        : (TILES * 2 <= 4 * NWV) ? 2 : 1;
-  constexpr int ROWS = 64 / SPLIT;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i = tid; i < CH * G; i += NT) L.mask[i] = 0ull;  // column words, OR-ed together in phase b
-  __syncthreads();
-  FRCNN_STAMP(10);
-
-  // ---- a. chunk vs kept list, four kept boxes per step -------------------------------------------
-  if (nk > 0) {
-    const int j = tid & (CH - 1);
-    const int slice = tid / CH;
-    if ((j & ~63) < nc) {  // wave-uniform: this wave's 64 candidates exist
-      const PBox me = load_pbox(L.c_box, L.c_area, L.c_flag, j);
-      bool d = false;
-      const unsigned long long valid_w = (nc - (j & ~63) >= 64) ? ~0ull : ((1ull << (nc - (j & ~63))) - 1ull);
-      const bool all_regular = L.s_nk[1] != 0 && (uniform64(~L.reg[j >> 6]) & valid_w) == 0ull && !thr.slow_only;
-      if (all_regular) {
-        // every kept box and every candidate of this wave is regular: packed band filter, four consecutive kept boxes per
-        // step (the kept list is padded with null boxes up to a multiple of 4; a null box suppresses nobody)
-        const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
-        const int ngroups = (nk + 3) >> 2;
-        for (int g4 = slice; g4 < ngroups; g4 += NSL) {
-          const float4 *kb = L.k_box + 4 * g4;
-          const float4 b0 = kb[0], b1 = kb[1], b2 = kb[2], b3 = kb[3];
-          const float4 ar = *reinterpret_cast<const float4 *>(L.k_area + 4 * g4);
-          const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
-          bool y0, y1, y2, y3, irr = false;
-          nms_iou_gt_fast2(meb, me.area, b0, b1, a01, thr.thr, y0, y1, irr);
-          nms_iou_gt_fast2(meb, me.area, b2, b3, a23, thr.thr, y2, y3, irr);
-          bool dd = y0 | y1 | y2 | y3;
-          if (__builtin_expect(ballot64(irr && j < nc) != 0ull, 0)) {  // inside the band: the reference formulation
-            const NBox men = to_nbox(me);
-            const float4 bb[4] = {b0, b1, b2, b3};
-            const float aa[4] = {ar.x, ar.y, ar.z, ar.w};
-            dd = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              NBox kn;
-              kn.ymin = bb[u].x;
-              kn.xmin = bb[u].y;
-              kn.ymax = bb[u].z;
-              kn.xmax = bb[u].w;
-              kn.area = aa[u];
-              dd = dd | nms_iou_gt(men, kn, thr.thr);
-            }
-          }
-          d = d | dd;
-          if (ballot64(!(d || (j >= nc))) == 0ull) break;
-        }
-      } else
-      for (int k0 = slice; k0 < nk; k0 += 4 * NSL) {
-        PBox kb[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          int k = k0 + u * NSL;
-          k = k < nk ? k : nk - 1;  // clamp: re-testing a kept box is harmless
-          kb[u] = load_pbox(L.k_box, L.k_area, L.k_flag, k);
-        }
-        bool irr = false, dd = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt_fast(me, kb[u], thr, irr);
-        if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
-          dd = false;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) dd = dd | nms_iou_gt(to_nbox(me), to_nbox(kb[u]), thr.thr);
-        }
-        d = d | dd;
-        if (ballot64(!(d || (j >= nc))) == 0ull) break;
-      }
-      const unsigned long long word = ballot64(d && (j < nc));
-      if (lane == 0 && word != 0ull) atomicOr(&L.dead[j >> 6], word);
-    }
-    __syncthreads();  // phase b skips the rows that are dead by now
-  }
-  FRCNN_STAMP(11);
-
-  // ---- b. intra-chunk IoU tiles (upper triangle) as COLUMN words ----------------------------------
-  // lane = column candidate; mask[col * G + rg] collects over the rows of row group rg the bits "row suppresses col and
-  // comes before it".  A work item is ROWS rows of one tile; rows already dead are skipped four at a time (a suppressed
-  // candidate suppresses nobody), partial words are OR-ed in LDS.
-  for (int item = w; item < TILES * SPLIT; item += NWV) {
-    const int tile = item / SPLIT;
-    const int part = item - tile * SPLIT;
-    // tile -> (rg, cg), cg >= rg, row-major over the upper triangle
-    int rg = 0, rem = tile;
-#pragma unroll
-    for (int r = 0; r < G; ++r) {
-      if (rg == r && rem >= G - rg) {
-        rem -= G - rg;
-        ++rg;
-      }
-    }
-    const int cg = rg + rem;
-    if (rg * 64 >= nc || cg * 64 >= nc) continue;  // wave-uniform
-    const int jcol = cg * 64 + lane;
-    const PBox me = load_pbox(L.c_box, L.c_area, L.c_flag, jcol);
-    const unsigned long long alive_rows = uniform64(~L.dead[rg]);
-    const unsigned long long reg_rows = uniform64(L.reg[rg]);
-    const bool cols_regular = ballot64(me.flag != (kFlagArea | kFlagRegular) && jcol < nc) == 0ull && !thr.slow_only;
-    static_assert(ROWS % 4 == 0, "rows per item must be a multiple of 4");
-    unsigned long long bits = 0ull;
-    for (int i0 = 0; i0 < ROWS; i0 += 4) {
-      const int rl0 = part * ROWS + i0;  // row offset inside the group
-      if (((alive_rows >> rl0) & 0xFull) == 0ull) continue;  // wave-uniform
-      const int irow0 = rg * 64 + rl0;
-      PBox rb[4];
-      bool bit[4];
-      if (cols_regular && ((reg_rows >> rl0) & 0xFull) == 0xFull) {  // wave-uniform: packed band filter
-        const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
-        const float4 r0 = L.c_box[irow0], r1 = L.c_box[irow0 + 1], r2 = L.c_box[irow0 + 2], r3 = L.c_box[irow0 + 3];
-        const float4 ar = *reinterpret_cast<const float4 *>(L.c_area + irow0);
-        const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
-        bool irr = false;
-        nms_iou_gt_fast2(meb, me.area, r0, r1, a01, thr.thr, bit[0], bit[1], irr);
-        nms_iou_gt_fast2(meb, me.area, r2, r3, a23, thr.thr, bit[2], bit[3], irr);
-        if (__builtin_expect(ballot64(irr) != 0ull, 0)) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            bit[u] = nms_iou_gt(to_nbox(load_pbox(L.c_box, L.c_area, L.c_flag, irow0 + u)), to_nbox(me), thr.thr);
-        }
-      } else {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) rb[u] = load_pbox(L.c_box, L.c_area, L.c_flag, irow0 + u);
-      bool irr = false;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt_fast(rb[u], me, thr, irr);
-      if (__builtin_expect(ballot64(irr || thr.slow_only) != 0ull, 0)) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(rb[u]), to_nbox(me), thr.thr);
-      }
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool hit = bit[u] & (irow0 + u < jcol) & (jcol < nc);
-        bits |= (unsigned long long)hit << (rl0 + u);
-      }
-    }
-    if (bits != 0ull) atomicOr(&L.mask[jcol * G + rg], bits);
-  }
-  __syncthreads();
-  FRCNN_STAMP(12);
-
-  // ---- c. greedy resolve on wave 0, one 64-candidate group at a time, in parallel rounds ------------------
-  // Lane i knows which earlier rows of its group suppress it (col).  A candidate hit by a KEPT row is removed; a
-  // candidate none of whose still-undecided earlier rows suppresses it is kept (whatever those rows turn out to be, they
-  // do not touch it).  The lowest undecided candidate always falls in one of the two classes, so every round makes
-  // progress; the fixed point is the sequential greedy result, reached in (longest suppression chain) rounds.
-  if (w == 0) {
-    unsigned long long deadw[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) deadw[g] = uniform64(L.dead[g]);
-    int cnt = nk;
-    int kreg = (nk == 0) ? 1 : L.s_nk[1];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int left = nc - g * 64;
-      if (left > 0 && cnt < R) {  // wave-uniform
-        const unsigned long long valid = (left >= 64) ? ~0ull : ((1ull << left) - 1ull);
-        const unsigned long long col = L.mask[(g * 64 + lane) * G + g];
-        unsigned long long und = ~deadw[g] & valid;
-        unsigned long long keptbits = 0ull;
-        while (und != 0ull) {
-          const bool in1 = (und >> lane) & 1ull;
-          und &= ~ballot64(in1 && (col & keptbits) != 0ull);
-          const bool in2 = (und >> lane) & 1ull;
-          const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
-          keptbits |= k;
-          und &= ~k;
-        }
-        if (cnt + __popcll(keptbits) > R) {  // the greedy scan stops at R: keep the first R - cnt of them
-          unsigned long long t = 0ull, bb = keptbits;
-          for (int k = cnt; k < R; ++k) {
-            const unsigned long long low = bb & (0ull - bb);
-            t |= low;
-            bb ^= low;
-          }
-          keptbits = t;
-        }
-        // the kept rows suppress into the later groups of the chunk
-#pragma unroll
-        for (int w2 = g + 1; w2 < G; ++w2)
-          if (w2 * 64 < nc) deadw[w2] |= ballot64((L.mask[(w2 * 64 + lane) * G + g] & keptbits) != 0ull);
-        if ((keptbits >> lane) & 1ull) {
-          const int pos = cnt + __popcll(keptbits & lanemask_lt());
-          const int j = g * 64 + lane;
-          L.k_box[pos] = L.c_box[j];
-          L.k_area[pos] = L.c_area[j];
-          L.k_flag[pos] = L.c_flag[j];
-          L.k_idx[pos] = L.c_idx[j];
-        }
-        cnt += __popcll(keptbits);
-        if ((keptbits & ~uniform64(L.reg[g])) != 0ull) kreg = 0;
-      }
-    }
-    // null boxes up to the next multiple of 4 (the packed kept-list tests read whole groups of four; the kept-list
-    // arrays hold a multiple of 4 entries)
-    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
-      L.k_box[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-      L.k_area[cnt + lane] = 0.0f;
-      L.k_flag[cnt + lane] = 0;
-    }
-    if (lane == 0) {
-      L.s_nk[0] = cnt;
-      L.s_nk[1] = kreg;
-    }
-  }
-  __syncthreads();
-  FRCNN_STAMP(13);
-  return L.s_nk[0];
-}
-
-// ---- a whole pre-decoded slice in chunks of 64, two barriers per chunk (the fused RoIBBox kernel) --------------------------
-// The slice's candidates stand in LDS in priority order: sbox / sarea / sflag / sidx, per 64 the words sbad ("fails the score
-// threshold") and sreg ("regular box"); the arrays are filled (zero boxes) up to a multiple of 64.  Against nms_chunk_resolve
-// at CH = 64: the intra-chunk tile of chunk c + 1 does not depend on chunk c's outcome, so waves 1.. compute it while wave 0
-// resolves chunk c (partial column words go to a double-buffered array of 16-bit pieces, one per (wave item, column): no
-// zeroing, no atomics); the kept-list tests of a chunk OR their ballots into a word that wave 0 preset with sbad.
-struct Slice64Lds {
-  unsigned long long *dead;  // [2]  dead word of the current / next chunk
-  uint16_t *part;            // [2][NT / 64][64]  partial column words: rows item * (4096 / NT) ... of the chunk's tile
-  int *s_nk;                 // [4]  [0] kept count, [1] every kept box so far is regular
-};
-template <int NT>
-__host__ __device__ static inline size_t slice64_lds_bytes() {
-  return 2 * 8 + 2 * (size_t)(NT / 64) * 64 * 2 + 4 * 4;
-}
-
+// ---- pair-test helpers shared by the chunk step and the slice loop ------------------------------------------------------
 struct KeptLds {
   float4 *box;  // [Rc] (Rc a multiple of 4; null boxes from the kept count up to the next multiple of 4)
   float *area;
@@ -572,6 +297,212 @@ __device__ __forceinline__ uint32_t tile_rows4(const float4 *box, const float *a
     }
   }
   return (uint32_t)bit[0] | ((uint32_t)bit[1] << 1) | ((uint32_t)bit[2] << 2) | ((uint32_t)bit[3] << 3);
+}
+
+// One chunk of nc (<= CH) candidates, in priority order, whose packed boxes (L.c_box, L.c_af), element indices (L.c_idx)
+// and initial dead words (L.dead[g]: candidates that fail the score threshold) are already in LDS -- written by this
+// workgroup, but not necessarily published yet: the function starts with a barrier.  L.c_* may point anywhere in LDS (a
+// slice decoded ahead of time); entries [nc, CH) are read but never influence a result.  nk = boxes kept so far; returns
+// the new count (<= R).  Must be called by all NT threads of the block.
+template <int NT, int CH>
+__device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr);
+
+// The same with the chunk loaded here: cand(j, box, ei, bad) fills candidate j's box (original corner order), element
+// index and "fails the score threshold" flag (called by threads j < nc).
+template <int NT, int CH, class CandF>
+__device__ __forceinline__ int nms_chunk(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr, CandF cand) {
+  static_assert(NT >= CH && NT % CH == 0, "block must cover the chunk");
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < CH) {
+    NBox nb;
+    nb.ymin = nb.xmin = nb.ymax = nb.xmax = nb.area = 0.0f;
+    int ei = -1, fl = 0;
+    bool bad = false;
+    if (tid < nc) {
+      float4 box;
+      cand(tid, box, ei, bad);
+      nb = normalise_box(box);
+      fl = box_flags(box, nb);
+    }
+    L.c_box[tid] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
+    L.c_area[tid] = nb.area;
+    L.c_flag[tid] = fl;
+    L.c_idx[tid] = ei;
+    const unsigned long long badw = ballot64(bad);  // candidates that fail the score threshold start dead
+    const unsigned long long regw = ballot64(fl == (kFlagArea | kFlagRegular));
+    if (lane == 0) {
+      L.dead[w] = badw;
+      L.reg[w] = regw;
+    }
+  }
+  return nms_chunk_resolve<NT, CH>(L, nc, nk, R, thr);
+}
+
+template <int NT, int CH>
+__device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, int nk, int R, const IouThr &thr) {
+  static_assert(CH == 64 || CH == 128 || CH == 256, "chunk must be 1, 2 or 4 waves wide");
+  static_assert(NT >= CH && NT % CH == 0, "block must cover the chunk");
+  constexpr int G = CH / 64;
+  constexpr int NWV = NT / 64;
+  constexpr int NSL = NT / CH;                  // slices of the kept list handled in parallel
+  constexpr int TILES = G * (G + 1) / 2;        // upper-triangular 64x64 tiles
+  // row splits per tile: the largest power of two (<= 16) that keeps the work items within 4 per wave
+  constexpr int SPLIT = (TILES * 16 <= 4 * NWV) ? 16 : (TILES * 8 <= 4 * NWV) ? 8 : (TILES * 4 <= 4 * NWV) ? 4
+                        : (TILES * 2 <= 4 * NWV) ? 2 : 1;
+  constexpr int ROWS = 64 / SPLIT;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < CH * G; i += NT) L.mask[i] = 0ull;  // column words, OR-ed together in phase b
+  __syncthreads();
+  FRCNN_STAMP(10);
+
+  // ---- a. chunk vs kept list, four kept boxes per step -------------------------------------------
+  if (nk > 0) {
+    const int j = tid & (CH - 1);
+    const int slice = tid / CH;
+    if ((j & ~63) < nc) {  // wave-uniform: this wave's 64 candidates exist
+      const PBox me = load_pbox(L.c_box, L.c_area, L.c_flag, j);
+      const unsigned long long valid_w = (nc - (j & ~63) >= 64) ? ~0ull : ((1ull << (nc - (j & ~63))) - 1ull);
+      // every kept box and every candidate of this wave regular: packed band filter (nms_iou_gt_fast2); the wave's share of
+      // the kept list is the groups slice, slice + NSL, ... of four kept boxes (null boxes pad the list to a multiple of 4)
+      const bool all_regular = L.s_nk[1] != 0 && (uniform64(~L.reg[j >> 6]) & valid_w) == 0ull && !thr.slow_only;
+      KeptLds kept;
+      kept.box = L.k_box;
+      kept.area = L.k_area;
+      kept.flag = L.k_flag;
+      kept.idx = L.k_idx;
+      const bool d = kept_list_hits(kept, me, j < nc, slice, NSL, nk, all_regular, thr);
+      const unsigned long long word = ballot64(d && (j < nc));
+      if (lane == 0 && word != 0ull) atomicOr(&L.dead[j >> 6], word);
+    }
+    __syncthreads();  // phase b skips the rows that are dead by now
+  }
+  FRCNN_STAMP(11);
+
+  // ---- b. intra-chunk IoU tiles (upper triangle) as COLUMN words ----------------------------------
+  // lane = column candidate; mask[col * G + rg] collects over the rows of row group rg the bits "row suppresses col and
+  // comes before it".  A work item is ROWS rows of one tile; rows already dead are skipped four at a time (a suppressed
+  // candidate suppresses nobody), partial words are OR-ed in LDS.
+  for (int item = w; item < TILES * SPLIT; item += NWV) {
+    const int tile = item / SPLIT;
+    const int part = item - tile * SPLIT;
+    // tile -> (rg, cg), cg >= rg, row-major over the upper triangle
+    int rg = 0, rem = tile;
+#pragma unroll
+    for (int r = 0; r < G; ++r) {
+      if (rg == r && rem >= G - rg) {
+        rem -= G - rg;
+        ++rg;
+      }
+    }
+    const int cg = rg + rem;
+    if (rg * 64 >= nc || cg * 64 >= nc) continue;  // wave-uniform
+    const int jcol = cg * 64 + lane;
+    const PBox me = load_pbox(L.c_box, L.c_area, L.c_flag, jcol);
+    const unsigned long long alive_rows = uniform64(~L.dead[rg]);
+    const unsigned long long reg_rows = uniform64(L.reg[rg]);
+    const bool cols_regular = ballot64(me.flag != (kFlagArea | kFlagRegular) && jcol < nc) == 0ull && !thr.slow_only;
+    static_assert(ROWS % 4 == 0, "rows per item must be a multiple of 4");
+    unsigned long long bits = 0ull;
+    for (int i0 = 0; i0 < ROWS; i0 += 4) {
+      const int rl0 = part * ROWS + i0;  // row offset inside the group
+      if (((alive_rows >> rl0) & 0xFull) == 0ull) continue;  // wave-uniform
+      const int irow0 = rg * 64 + rl0;
+      const bool packed = cols_regular && ((reg_rows >> rl0) & 0xFull) == 0xFull;  // wave-uniform
+      const uint32_t nib = tile_rows4(L.c_box, L.c_area, L.c_flag, irow0, me, packed, thr);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool hit = ((nib >> u) & 1u) && (irow0 + u < jcol) && (jcol < nc);
+        bits |= (unsigned long long)hit << (rl0 + u);
+      }
+    }
+    if (bits != 0ull) atomicOr(&L.mask[jcol * G + rg], bits);
+  }
+  __syncthreads();
+  FRCNN_STAMP(12);
+
+  // ---- c. greedy resolve on wave 0, one 64-candidate group at a time, in parallel rounds ------------------
+  // Lane i knows which earlier rows of its group suppress it (col).  A candidate hit by a KEPT row is removed; a
+  // candidate none of whose still-undecided earlier rows suppresses it is kept (whatever those rows turn out to be, they
+  // do not touch it).  The lowest undecided candidate always falls in one of the two classes, so every round makes
+  // progress; the fixed point is the sequential greedy result, reached in (longest suppression chain) rounds.
+  if (w == 0) {
+    unsigned long long deadw[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) deadw[g] = uniform64(L.dead[g]);
+    int cnt = nk;
+    int kreg = (nk == 0) ? 1 : L.s_nk[1];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int left = nc - g * 64;
+      if (left > 0 && cnt < R) {  // wave-uniform
+        const unsigned long long valid = (left >= 64) ? ~0ull : ((1ull << left) - 1ull);
+        const unsigned long long col = L.mask[(g * 64 + lane) * G + g];
+        unsigned long long und = ~deadw[g] & valid;
+        unsigned long long keptbits = 0ull;
+        while (und != 0ull) {
+          const bool in1 = (und >> lane) & 1ull;
+          und &= ~ballot64(in1 && (col & keptbits) != 0ull);
+          const bool in2 = (und >> lane) & 1ull;
+          const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
+          keptbits |= k;
+          und &= ~k;
+        }
+        if (cnt + __popcll(keptbits) > R) {  // the greedy scan stops at R: keep the first R - cnt of them
+          unsigned long long t = 0ull, bb = keptbits;
+          for (int k = cnt; k < R; ++k) {
+            const unsigned long long low = bb & (0ull - bb);
+            t |= low;
+            bb ^= low;
+          }
+          keptbits = t;
+        }
+        // the kept rows suppress into the later groups of the chunk
+#pragma unroll
+        for (int w2 = g + 1; w2 < G; ++w2)
+          if (w2 * 64 < nc) deadw[w2] |= ballot64((L.mask[(w2 * 64 + lane) * G + g] & keptbits) != 0ull);
+        if ((keptbits >> lane) & 1ull) {
+          const int pos = cnt + __popcll(keptbits & lanemask_lt());
+          const int j = g * 64 + lane;
+          L.k_box[pos] = L.c_box[j];
+          L.k_area[pos] = L.c_area[j];
+          L.k_flag[pos] = L.c_flag[j];
+          L.k_idx[pos] = L.c_idx[j];
+        }
+        cnt += __popcll(keptbits);
+        if ((keptbits & ~uniform64(L.reg[g])) != 0ull) kreg = 0;
+      }
+    }
+    // null boxes up to the next multiple of 4 (the packed kept-list tests read whole groups of four; the kept-list
+    // arrays hold a multiple of 4 entries)
+    if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {
+      L.k_box[cnt + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      L.k_area[cnt + lane] = 0.0f;
+      L.k_flag[cnt + lane] = 0;
+    }
+    if (lane == 0) {
+      L.s_nk[0] = cnt;
+      L.s_nk[1] = kreg;
+    }
+  }
+  __syncthreads();
+  FRCNN_STAMP(13);
+  return L.s_nk[0];
+}
+
+// ---- a whole pre-decoded slice in chunks of 64, two barriers per chunk (the fused RoIBBox kernel) --------------------------
+// The slice's candidates stand in LDS in priority order: sbox / sarea / sflag / sidx, per 64 the words sbad ("fails the score
+// threshold") and sreg ("regular box"); the arrays are filled (zero boxes) up to a multiple of 64.  Against nms_chunk_resolve
+// at CH = 64: the intra-chunk tile of chunk c + 1 does not depend on chunk c's outcome, so waves 1.. compute it while wave 0
+// resolves chunk c (partial column words go to a double-buffered array of 16-bit pieces, one per (wave item, column): no
+// zeroing, no atomics); the kept-list tests of a chunk OR their ballots into a word that wave 0 preset with sbad.
+struct Slice64Lds {
+  unsigned long long *dead;  // [2]  dead word of the current / next chunk
+  uint16_t *part;            // [2][NT / 64][64]  partial column words: rows item * (4096 / NT) ... of the chunk's tile
+  int *s_nk;                 // [4]  [0] kept count, [1] every kept box so far is regular
+};
+template <int NT>
+__host__ __device__ static inline size_t slice64_lds_bytes() {
+  return 2 * 8 + 2 * (size_t)(NT / 64) * 64 * 2 + 4 * 4;
 }
 
 // Returns the new kept count.  Must be called by all NT threads; the slice arrays must be published (a barrier behind
