@@ -113,7 +113,14 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
   // The image's class probabilities are staged once, coalesced, in the (not yet used) sort buffer: phase A reads every row
   // twice, and a lane walking its own 84-byte row straight from memory pays two uncoalesced round trips.
   float *sprob = reinterpret_cast<float *>(perm);  // [R*L] <= 4*Vcap bytes
-  for (int i = tid; i < R * L; i += kNT) sprob[i] = probs[i];
+  for (int i0 = tid; i0 < R * L; i0 += 8 * kNT) {  // eight loads per thread in flight
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + u * kNT < R * L) ? probs[i0 + u * kNT] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * kNT < R * L) sprob[i0 + u * kNT] = v[u];
+  }
   __syncthreads();
 
   // ---- A. candidates, compacted in (roi, class) order -------------------------------------------------

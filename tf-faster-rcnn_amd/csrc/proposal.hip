@@ -105,12 +105,27 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
 
   FRCNN_STAMP(0);
   if (tid == 0) misc[9] = 0;  // misc[9] = a bucket of the fast slice sort overflowed
-  if (cache_keys == 1) {
-    for (int i = tid; i < N; i += kNT) kcache[i] = ~f_order_key(scores[i]);
-  } else if (cache_keys == 2) {
-    // N beyond what LDS holds as 32-bit keys (config 5: 35721): the fast slices decide membership from the upper 16 bits
-    // alone, so those are what is cached; the full key is fetched for the members of a slice only
-    for (int i = tid; i < N; i += kNT) kc16[i] = (uint16_t)(~f_order_key(scores[i]) >> 16);
+  if (cache_keys) {
+    // eight loads per thread in flight (the compiler unrolls this loop by two and waits for every pair: with inputs that
+    // come from HBM, not L2, that is 2 us per pair).  cache_keys == 2: N beyond what LDS holds as 32-bit keys (config 5:
+    // 35721) -- the fast slices decide membership from the upper 16 bits alone, so those are what is cached; the full key
+    // is fetched for the members of a slice only.
+    for (int i0 = tid; i0 < N; i0 += 8 * kNT) {
+      float sc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sc[u] = (i0 + u * kNT < N) ? scores[i0 + u * kNT] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * kNT;
+        if (i < N) {
+          const uint32_t k = ~f_order_key(sc[u]);
+          if (cache_keys == 1)
+            kcache[i] = k;
+          else
+            kc16[i] = (uint16_t)(k >> 16);
+        }
+      }
+    }
   }
   __syncthreads();
   bool fast = fast_slices != 0 && N <= 64 * kNT;  // (a thread's elements are the bits of one 64-bit mask)
