@@ -39,6 +39,24 @@ for it in range(3):
             print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
 
 
+if len(sys.argv) >= 5 and sys.argv[4] == "cold":
+    # the same kernel on inputs that are not in any cache: 40 input sets (> 256 MiB Infinity Cache with the filler) in turn
+    sets = []
+    for k in range(24):
+        dk, sk = synth.rpn_outputs(100 + k, 16, G_)
+        sets.append((torch.as_tensor(dk).cuda(), torch.as_tensor(sk).cuda()))
+    filler = torch.empty(512 * 1024 * 1024 // 4, device="cuda")
+    for k in range(24):
+        filler.add_(1.0)  # sweeps 512 MiB through the caches
+        torch.cuda.synchronize()
+        lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+        layer(list(sets[k]))
+        torch.cuda.synchronize()
+    n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+    print("---- cold inputs ----")
+    for i in range(n):
+        print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
 if len(sys.argv) >= 4:
     sys.exit(0)
 
