@@ -271,6 +271,33 @@ def test_top_k(pkg, B, N, K):
     assert_bits(vals, wv, "top_k values")
 
 
+def test_top_k_score_distributions(pkg, knobs):
+    """The full-sort kernel orders its slots with a bucket sort (buckets linear in the score, then in the key's bit pattern)
+    and falls back to the stable radix sort when a bucket overflows: distributions that take each of the three routes,
+    non-finite scores included, with and without the bucket sort."""
+    rng = np.random.default_rng(77)
+    B, N, K = 3, 9000, 6000
+    dists = {
+        "uniform": lambda: rng.random((B, N)),
+        "log_uniform": lambda: np.exp(-40.0 * rng.random((B, N))),
+        "sigmoid_saturated": lambda: 1.0 / (1.0 + np.exp(-8.0 * rng.normal(0, 1, (B, N)))),
+        "signed_wide": lambda: rng.normal(0, 1e10, (B, N)),
+        "constant": lambda: np.full((B, N), 0.5),
+        "few_values": lambda: rng.choice(rng.random(20), (B, N)),
+        "tight_cluster": lambda: 0.25 + 1e-7 * rng.random((B, N)),
+        "with_inf_nan": lambda: np.where(rng.random((B, N)) < 0.01, rng.choice([np.inf, -np.inf, np.nan], (B, N)), rng.random((B, N))),
+        "huge_range": lambda: rng.choice([1e38, -1e38, 1e-38, 0.0], (B, N)) * rng.random((B, N)),
+    }
+    for name, draw in dists.items():
+        s = draw().astype(np.float32)
+        wv, wi = oracle.top_k(s, K)
+        for radix_only in (0, 1):
+            knobs.setenv("FRCNN_SORT_RADIX_ONLY", radix_only)
+            vals, idx = pkg.bbox_utils.top_k(dev(s), K)
+            assert_bits(idx, wi, f"top_k indices, scores={name}, radix_only={radix_only}")
+            assert_bits(vals, wv, f"top_k values, scores={name}, radix_only={radix_only}")
+
+
 def test_top_k_ties_and_errors(pkg):
     rng = np.random.default_rng(11)
     s = rng.integers(0, 8, size=(4, 3000)).astype(np.float32) / 8.0  # heavy ties -> ascending index

@@ -309,9 +309,12 @@ __device__ __forceinline__ int block_sort_digits(DigitF digit, int npass, uint16
 // the many buckets.  Pays when the keys spread, not when they cluster: returns false -- perm undefined -- when a bucket
 // holds more than 48 slots, and the caller sorts by radix instead.
 // perm: [V] out; place: [V] scratch; hist: 4 * NT uint32; wsum: NT / 64 ints; misc: >= 10 ints (uses [6], [7], [9]).  V < 65536.
+// by_value: the keys are ~f_order_key(score) and the buckets are linear in the SCORE instead of in the key's bit pattern
+// (fp32 bit patterns are log-spaced across binades: uniformly distributed scores put half the slots into the top
+// binade's share of key-linear buckets); refused (false) when the lowest or highest key is not a finite score.
 template <int NT = kNT>
 __device__ __forceinline__ bool block_bucket_sort_perm(const uint32_t *keys, uint16_t *perm, uint16_t *place, int V,
-                                                       uint32_t *hist, int *wsum, int *misc) {
+                                                       uint32_t *hist, int *wsum, int *misc, bool by_value = false) {
   constexpr int NBK = 8 * NT;
   uint16_t *start = reinterpret_cast<uint16_t *>(hist);  // [NBK] counters, then bucket starts
   const int tid = threadIdx.x;
@@ -340,10 +343,20 @@ __device__ __forceinline__ bool block_bucket_sort_perm(const uint32_t *keys, uin
     atomicMax(reinterpret_cast<uint32_t *>(&misc[7]), hi);
   }
   __syncthreads();
-  const uint32_t kmin = (uint32_t)misc[6];
-  const float scale = (float)NBK / ((float)((uint32_t)misc[7] - kmin) + 1.0f);
+  const uint32_t kmin = (uint32_t)misc[6], kmax = (uint32_t)misc[7];
+  // score of a key: the inverse of ~f_order_key (non-negative floats carry the top bit in the order key)
+  auto value_of = [](uint32_t k) -> float {
+    const uint32_t o = ~k;
+    return u2f((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+  };
+  const float fmax = value_of(kmin), fmin = value_of(kmax);  // ascending key = descending score
+  if (by_value && !(fabsf(fmax) <= 3.402823466e+38f && fabsf(fmin) <= 3.402823466e+38f)) return false;  // block-uniform
+  const float scale = by_value ? (float)NBK / (fmax - fmin) : (float)NBK / ((float)(kmax - kmin) + 1.0f);
   auto bucket_of = [&](uint32_t k) -> int {
-    const int bkt = (int)((float)(k - kmin) * scale);  // monotone in k
+    // monotone in k either way (a subtraction from a constant, a product with a positive constant, a truncation);
+    // scale = inf (one distinct score) makes 0 * inf = NaN -> bucket 0 for the slot(s) at fmax, the last bucket otherwise
+    const float x = by_value ? (fmax - value_of(k)) * scale : (float)(k - kmin) * scale;
+    const int bkt = (x >= 0.0f) ? (int)fminf(x, (float)(NBK - 1)) : 0;
     return bkt < NBK - 1 ? bkt : NBK - 1;
   };
   for (int j = tid; j < V; j += NT) {

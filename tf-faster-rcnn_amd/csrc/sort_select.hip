@@ -11,7 +11,8 @@
 //      histogram, global re-reads that stay in L2) finds the key of the K-th best element;
 //   2. the surviving elements are compacted into LDS in index order (blocked prefix scan), keyed by
 //      ~order_key(score) so that ascending key == descending score;
-//   3. the slots are ordered by (key, slot) with a bucket sort (block_primitives.hpp); when the keys cluster (a bucket
+//   3. the slots are ordered by (key, slot) with a bucket sort (block_primitives.hpp: buckets linear in the score first,
+//      linear in the key's bit pattern second); when the keys cluster either way (a bucket
 //      overflows) a 4-pass, 8-bit, least-significant-digit radix sort permutes 16-bit slot numbers instead.  Stability
 //      is what yields "equal scores by ascending index": each wave owns a contiguous slice of the
 //      current order, counts its digits with LDS adds, the 256x16 counters are scanned digit-major /
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
     if (tid == 0 && counts) counts[seg] = 0;
     return;
   }
+  FRCNN_STAMP(40);
 
   auto keyf = [&](int i, uint32_t &k) -> bool {
     const float s = load_score(src, b, i, cls);
@@ -118,13 +120,16 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
     if (V > slots) V = slots;  // defensive; cannot happen
   }
 
+  FRCNN_STAMP(41);
   // ---- 3. order the V slots by (key, slot): bucket sort; stable LSD radix sort when the keys cluster ----------------
-  if (no_bucket_sort || !block_bucket_sort_perm(keys, permA, permA + slots, V, hist, wsum, misc)) {
+  if (no_bucket_sort || !(block_bucket_sort_perm(keys, permA, permA + slots, V, hist, wsum, misc, true) ||
+                          block_bucket_sort_perm(keys, permA, permA + slots, V, hist, wsum, misc, false))) {
     __syncthreads();
     for (int i = tid; i < V; i += kNT) permA[i] = (uint16_t)i;
     block_sort_perm(keys, permA, slots, V, hist, wsum);
   }
   const uint16_t *perm = permA;
+  FRCNN_STAMP(42);
 
   // ---- 4. emit ------------------------------------------------------------------------------------
   const int nout = (V < K) ? V : K;
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(1024) void sort_select_kernel(ScoreSource src, int 
     if (sorted_val) sorted_val[(long long)seg * out_stride + r] = load_score(src, b, i, cls);
   }
   if (tid == 0 && counts) counts[seg] = nout;
+  FRCNN_STAMP(43);
 }
 
 static size_t sort_lds_bytes(int slots, size_t idx_bytes) {
