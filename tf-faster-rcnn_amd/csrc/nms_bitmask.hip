@@ -18,6 +18,9 @@
 //         (one AND and one ballot).
 //      An image that has its R boxes (or runs out of candidates) writes its outputs and marks itself done; later phases
 //      return at once for it, so the work is proportional to the candidates actually consumed, in bands of 2048.
+//      Launch order: a band's (b) tiles do not depend on the scans before it, so they are computed one band AHEAD, by
+//      extra workgroups of the previous band's scan launch (`bm_scan_tiles_kernel`: the scan is one latency-bound
+//      workgroup per image, the rest of the chip is free); what runs between two scans is only the (a) tiles.
 // All state between kernels lives in the caller's workspace; nothing synchronises with the host.
 #include <stdlib.h>
 
@@ -118,18 +121,11 @@ __device__ __forceinline__ unsigned long long tile_column_word(const float4 *row
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// grid (band column blocks, ceil((gx + band blocks) / 4), B), block 256: wave w <-> row group g = 4*blockIdx.y + w.
-// Groups g < gx are 64 kept boxes of earlier bands (gx = host-side bound on their number / 64); the others are the band's
-// own blocks rb = cb0 + g - gx.
-__global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0, int gx) {
-  __shared__ float4 s_box[4][64];
-  __shared__ float2 s_af[4][64];
-  const int b = blockIdx.z;
-  if (p.state[b * 4 + 1]) return;  // image finished in an earlier phase
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int cb = cb0 + blockIdx.x;
-  const int g = blockIdx.y * 4 + w;
-  if (cb >= p.nb) return;
+// One 64x64 tile by one wave: column block cb of image b against row group g -- for g < gx the g-th 64 of the boxes KEPT in
+// earlier bands (cross tile -> xmask), otherwise block rb = cb0 + (g - gx) of the column's own band (-> mask; the diagonal
+// tile rb == cb only counts rows before the column).  s_box / s_af: 64 entries of this wave's own LDS.
+__device__ __forceinline__ void bm_tile(const BitmaskParams &p, int b, int cb, int g, int cb0, int gx, int lane, float4 *s_box,
+                                        float2 *s_af) {
   const int Kp = p.nb * 64;
   const float4 *pbox = p.pbox + (long long)b * Kp;
   const float2 *paf = p.paf + (long long)b * Kp;
@@ -151,8 +147,8 @@ __global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0,
     rbox = pbox[row_pos];
     raf = paf[row_pos];
   }
-  s_box[w][lane] = rbox;
-  s_af[w][lane] = raf;
+  s_box[lane] = rbox;
+  s_af[lane] = raf;
   const int jcol = cb * 64 + lane;
   const PBox me = load_pbox(pbox, paf, jcol);
   // wave-private LDS rows: LDS operations of a wave complete in order; keep the compiler from hoisting the reads
@@ -162,21 +158,35 @@ __global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0,
   // rows of earlier bands and of earlier blocks all precede the column; inside the diagonal tile only rows before it count
   unsigned long long word;
   if (!cross && rb == cb)
-    word = tile_column_word<true>(s_box[w], s_af[w], me, p.iou, lane);
+    word = tile_column_word<true>(s_box, s_af, me, p.iou, lane);
   else
-    word = tile_column_word<false>(s_box[w], s_af[w], me, p.iou, lane);
+    word = tile_column_word<false>(s_box, s_af, me, p.iou, lane);
   if (cross)
     p.xmask[((long long)b * p.nb + cb) * p.Rx + g * 64 + lane] = word;
   else
     p.mask[((long long)b * p.nb + cb) * (kBandBlocks * 64) + (rb - cb0) * 64 + lane] = word;
 }
 
+// grid (band column blocks, ceil(row groups / 4), B), block 256: wave w <-> row group g = 4*blockIdx.y + w.
+// Groups g < gx are 64 kept boxes of earlier bands (gx = host-side bound on their number / 64); the others are the band's
+// own blocks rb = cb0 + g - gx (not launched / skipped with cross_only: those tiles are computed one band ahead, beside
+// the previous band's scan).
+__global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0, int gx, int cross_only) {
+  __shared__ float4 s_box[4][64];
+  __shared__ float2 s_af[4][64];
+  const int b = blockIdx.z;
+  if (p.state[b * 4 + 1]) return;  // image finished in an earlier phase
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cb = cb0 + blockIdx.x;
+  const int g = blockIdx.y * 4 + w;
+  if (cb >= p.nb) return;
+  if (cross_only && g >= gx) return;
+  bm_tile(p, b, cb, g, cb0, gx, lane, s_box[w], s_af[w]);
+}
+
 // One workgroup (1024 threads) per image.  LDS: removed[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
-__global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
-  __shared__ unsigned long long s_kept[2];  // double-buffered: wave 0 runs one block ahead of the waves that read them
-  __shared__ int s_nk[2];
-  const int b = blockIdx.x;
+__device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int cb0, int last_phase,
+                                              unsigned long long *s_words, unsigned long long *s_kept, int *s_nk) {
   if (p.state[b * 4 + 1]) return;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nb = p.nb, R = p.R_nms;
@@ -310,6 +320,39 @@ __global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0,
   }
 }
 
+__global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
+  __shared__ unsigned long long s_kept[2];  // double-buffered: wave 0 runs one block ahead of the waves that read them
+  __shared__ int s_nk[2];
+  bm_scan_image(p, blockIdx.x, cb0, last_phase, s_words, s_kept, s_nk);
+}
+
+// The scan of band [cb0, ...) beside the NEXT band's own tiles, which do not depend on it: workgroups 0 .. B-1 scan, the
+// others are 16 waves with one (image, column block, row block) tile of band [nb0, nb0 + nbn) each (row block <= column
+// block; the other half of the square returns at once).  An image that finishes in this very scan has its next-band tiles
+// computed for nothing; images finished earlier are skipped.
+__global__ __launch_bounds__(1024) void bm_scan_tiles_kernel(BitmaskParams p, int cb0, int B, int nb0, int nbn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
+  __shared__ unsigned long long s_kept[2];
+  __shared__ int s_nk[2];
+  __shared__ float4 s_box[16][64];
+  __shared__ float2 s_af[16][64];
+  if ((int)blockIdx.x < B) {
+    bm_scan_image(p, blockIdx.x, cb0, 0, s_words, s_kept, s_nk);
+    return;
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long long t = ((long long)blockIdx.x - B) * 16 + w;
+  const int per_image = nbn * nbn;
+  const int b = (int)(t / per_image);
+  if (b >= B) return;
+  const int rem = (int)(t - (long long)b * per_image);
+  const int cbi = rem / nbn, rbi = rem - cbi * nbn;
+  if (rbi > cbi) return;
+  if (p.state[b * 4 + 1]) return;  // finished in an earlier phase
+  bm_tile(p, b, nb0 + cbi, rbi, nb0, 0, lane, s_box[w], s_af[w]);
+}
+
 struct BitmaskWorkspace {
   int *sorted_idx;
   int *counts;
@@ -409,16 +452,38 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
     rc = ensure_dynamic_lds(reinterpret_cast<const void *>(scan), lds, "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
   }
+  auto scan_tiles = bm_scan_tiles_kernel;
+  if (lds > 48 * 1024) {
+    rc = ensure_dynamic_lds(reinterpret_cast<const void *>(scan_tiles), lds, "roi_bbox: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  // Schedule: the first band's own tiles; then per band [cross tiles against the boxes kept so far] and [scan ‖ the next
+  // band's own tiles] -- a band's own tiles do not depend on the scans before it, so they run beside the previous scan
+  // (one workgroup per image, latency bound) instead of in front of their own.
+  {
+    const int nb0 = kBandBlocks < p.nb ? kBandBlocks : p.nb;
+    hipLaunchKernelGGL(bm_tiles_kernel, dim3((unsigned)nb0, (unsigned)((nb0 + 3) / 4), (unsigned)B), dim3(256), 0, stream, p, 0, 0, 0);
+    rc = check_launch("roi_bbox (bitmask tiles)");
+    if (rc) return rc;
+  }
   for (int cb0 = 0; cb0 < p.nb; cb0 += kBandBlocks) {
     const int cb1 = (cb0 + kBandBlocks < p.nb) ? cb0 + kBandBlocks : p.nb;
     // at most min(R_nms, cb0 * 64) boxes were kept before this band
     const int kept_bound = (R_nms < cb0 * 64) ? R_nms : cb0 * 64;
     const int gx = (kept_bound + 63) / 64;
-    hipLaunchKernelGGL(bm_tiles_kernel, dim3((unsigned)(cb1 - cb0), (unsigned)((gx + (cb1 - cb0) + 3) / 4), (unsigned)B), dim3(256),
-                       0, stream, p, cb0, gx);
-    rc = check_launch("roi_bbox (bitmask tiles)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(scan, dim3((unsigned)B), dim3(1024), lds, stream, p, cb0, cb1 >= p.nb ? 1 : 0);
+    if (gx > 0) {
+      hipLaunchKernelGGL(bm_tiles_kernel, dim3((unsigned)(cb1 - cb0), (unsigned)((gx + 3) / 4), (unsigned)B), dim3(256), 0, stream,
+                         p, cb0, gx, 1);
+      rc = check_launch("roi_bbox (bitmask cross tiles)");
+      if (rc) return rc;
+    }
+    if (cb1 >= p.nb) {
+      hipLaunchKernelGGL(scan, dim3((unsigned)B), dim3(1024), lds, stream, p, cb0, 1);
+    } else {
+      const int nbn = (cb1 + kBandBlocks < p.nb) ? kBandBlocks : p.nb - cb1;  // column blocks of the next band
+      const long long tile_wgs = ((long long)B * nbn * nbn + 15) / 16;
+      hipLaunchKernelGGL(scan_tiles, dim3((unsigned)(B + tile_wgs)), dim3(1024), lds, stream, p, cb0, B, cb1, nbn);
+    }
     rc = check_launch("roi_bbox (bitmask scan)");
     if (rc) return rc;
   }
