@@ -357,9 +357,16 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
     if (part < parts && q < V) {
       mine = kcomp[q];
       if (mine != ~0ull) {
-        const int j0 = (int)((long long)V * part / parts), j1 = (int)((long long)V * (part + 1) / parts);
+        // slice boundaries on even positions: two keys per 16-byte LDS read
+        const int j0 = ((int)((long long)V * part / parts)) & ~1;
+        const int j1e = (part + 1 == parts) ? V : (((int)((long long)V * (part + 1) / parts)) & ~1);
         int rank = 0;
-        for (int j = j0; j < j1; ++j) rank += kcomp[j] < mine;  // (~0 = not kept: never smaller)
+        int j = j0;
+        for (; j + 1 < j1e; j += 2) {
+          const ulonglong2 two = *reinterpret_cast<const ulonglong2 *>(kcomp + j);
+          rank += (two.x < mine) + (two.y < mine);  // (~0 = not kept: never smaller)
+        }
+        if (j < j1e) rank += kcomp[j] < mine;
         if (rank) atomicAdd(&racc[q], (uint32_t)rank);
       }
     }
