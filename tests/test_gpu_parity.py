@@ -476,6 +476,20 @@ def test_roi_bbox_dense_suppression(pkg):
     assert_bits(got, want, "RoIBBox dense")
 
 
+def test_roi_bbox_more_anchors_than_the_key_cache_and_member_masks_hold(pkg, knobs):
+    """N = 72,900 anchors: no LDS key cache in any form and more elements per thread than the fast slices' 64-bit member
+    masks cover, so the fused kernel runs on exact-rank slices with keys from global memory."""
+    G, K, R = 90, 3000, 100
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R)
+    anchors = oracle.generate_anchors(hp)
+    deltas, scores = synth.rpn_outputs(41, 1, G)
+    knobs.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "0")
+    got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+    want = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, 0.7)
+    assert_bits(got, want, "RoIBBox N=72900")
+
+
 def test_roi_bbox_k_gt_n_raises(pkg):
     with pytest.raises(ValueError):
         _roi_bbox_case(pkg, 0, 1, 4, 1000, 10)
