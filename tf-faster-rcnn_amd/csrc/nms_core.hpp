@@ -493,16 +493,16 @@ __device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, in
 // The slice's candidates stand in LDS in priority order: sbox / sarea / sflag / sidx, per 64 the words sbad ("fails the score
 // threshold") and sreg ("regular box"); the arrays are filled (zero boxes) up to a multiple of 64.  Against nms_chunk_resolve
 // at CH = 64: the intra-chunk tile of chunk c + 1 does not depend on chunk c's outcome, so waves 1.. compute it while wave 0
-// resolves chunk c (partial column words go to a double-buffered array of 16-bit pieces, one per (wave item, column): no
-// zeroing, no atomics); the kept-list tests of a chunk OR their ballots into a word that wave 0 preset with sbad.
+// resolves chunk c (the tile waves OR their pieces into double-buffered column words, cleared a phase ahead, so that the
+// resolve reads one word per column); the kept-list tests of a chunk OR their ballots into a word that wave 0 preset with sbad.
 struct Slice64Lds {
   unsigned long long *dead;  // [2]  dead word of the current / next chunk
-  uint16_t *part;            // [2][NT / 64][64]  partial column words: rows item * (4096 / NT) ... of the chunk's tile
+  unsigned long long *colw;  // [2][64]  column words of the current / next chunk's tile (OR-ed together by the tile waves)
   int *s_nk;                 // [4]  [0] kept count, [1] every kept box so far is regular
 };
 template <int NT>
 __host__ __device__ static inline size_t slice64_lds_bytes() {
-  return 2 * 8 + 2 * (size_t)(NT / 64) * 64 * 2 + 4 * 4;
+  return 2 * 8 + 2 * 64 * 8 + 4 * 4;
 }
 
 // Returns the new kept count.  Must be called by all NT threads; the slice arrays must be published (a barrier behind
@@ -538,9 +538,11 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
       const uint32_t order = before <= 0 ? 0u : (before >= ROWS ? ((1u << ROWS) - 1u) : ((1u << before) - 1u));
       bits &= (lane < nc) ? order : 0u;
     }
-    T.part[((c & 1) * NWV + item) * 64 + lane] = (uint16_t)bits;
+    if (bits != 0u) atomicOr(&T.colw[(c & 1) * 64 + lane], (unsigned long long)bits << r0);
   };
 
+  if (tid < 128) T.colw[tid] = 0ull;
+  __syncthreads();
   if (nchunks > 0) tile_item(0, w);
   if (tid == 0) {
     T.dead[0] = sbad[0];
@@ -551,6 +553,7 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
   for (int c = 0; c < nchunks && nk < R; ++c) {
     const int cbase = c << 6;
     const int nc = (V - cbase < 64) ? (V - cbase) : 64;
+    if (w == 1) T.colw[((c + 1) & 1) * 64 + lane] = 0ull;  // the next chunk's words (last read two barriers ago)
     // ---- a. the chunk against the kept list: wave w takes the groups w, w + NWV, ... of four kept boxes -------------
     if (nk > 0) {
       const PBox me = load_pbox(sbox, sarea, sflag, cbase + lane);
@@ -568,10 +571,7 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
       // ---- c. greedy resolve of the chunk in parallel rounds (see nms_chunk_resolve) ---------------------------------
       const unsigned long long deadw = uniform64(T.dead[c & 1]);
       const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
-      unsigned long long col = 0ull;
-#pragma unroll
-      for (int it = 0; it < NWV; ++it)
-        col |= (unsigned long long)T.part[((c & 1) * NWV + it) * 64 + lane] << (it * ROWS);
+      const unsigned long long col = T.colw[(c & 1) * 64 + lane];
       unsigned long long und = ~deadw & valid;
       unsigned long long keptbits = 0ull;
       while (und != 0ull) {
@@ -611,6 +611,7 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
         if ((keptbits & ~uniform64(sreg[c])) != 0ull) T.s_nk[1] = 0;
         if (c + 1 < nchunks) T.dead[(c + 1) & 1] = sbad[c + 1];
       }
+      FRCNN_STAMP(14);
     } else if (c + 1 < nchunks) {
       // ---- b. meanwhile: the next chunk's tile, items 0 .. NWV - 1 over the waves 1 .. NWV - 1 (wave 1 takes two) ------
       tile_item(c + 1, w - 1);

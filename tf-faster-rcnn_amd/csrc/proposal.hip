@@ -82,8 +82,8 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
   unsigned long long *sreg = sbad + S / 64;                    // [S/64] "regular box"
   Slice64Lds T64;
   T64.dead = sreg + S / 64;
-  T64.part = reinterpret_cast<uint16_t *>(T64.dead + 2);
-  T64.s_nk = reinterpret_cast<int *>(T64.part + 2 * kNW * 64);
+  T64.colw = T64.dead + 2;
+  T64.s_nk = reinterpret_cast<int *>(T64.colw + 2 * 64);
   uint32_t *kcache = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(sreg + S / 64) +
                                                   ((slice64_lds_bytes<NT>() + 15) & ~(size_t)15));  // [N] when cache_keys == 1
   uint16_t *kc16 = reinterpret_cast<uint16_t *>(kcache);           // [N] when cache_keys == 2: the keys' upper halves only
