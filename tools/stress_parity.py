@@ -1,0 +1,119 @@
+"""Randomised parity stress beyond the fixed-seed tests: RoIBBox / Decoder / RPN targets against the CPU oracle with fresh
+seeds, shapes and score distributions for a given number of seconds.  Test infrastructure (uses oracle/); prints the first
+mismatch and exits 1, or a summary.
+
+    python tools/stress_parity.py [seconds] [seed]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+import oracle
+import synth
+import tf_faster_rcnn_amd as pkg
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = np.random.default_rng(seed)
+print("seed", seed, flush=True)
+
+
+def dev(a):
+    return torch.as_tensor(a).cuda()
+
+
+def same(got, want, what):
+    g = got.detach().cpu().numpy()
+    if g.shape != want.shape or not np.array_equal(g.view(np.uint32), np.ascontiguousarray(want).view(np.uint32)):
+        print("MISMATCH", what, flush=True)
+        sys.exit(1)
+
+
+def scores_like(shape):
+    kind = rng.integers(0, 7)
+    if kind == 0:
+        return rng.random(shape)
+    if kind == 1:
+        return 1.0 / (1.0 + np.exp(-rng.uniform(1, 10) * rng.normal(0, 1, shape)))
+    if kind == 2:
+        return rng.choice(rng.random(int(rng.integers(1, 50))), shape)
+    if kind == 3:
+        return np.exp(-rng.uniform(1, 60) * rng.random(shape))
+    if kind == 4:
+        return rng.normal(0, 10.0 ** rng.integers(-3, 6), shape)
+    if kind == 5:
+        return np.where(rng.random(shape) < 0.5, rng.random(), rng.random(shape))
+    return 0.5 + 10.0 ** rng.integers(-7, -1) * rng.random(shape)
+
+
+lib = pkg._lib
+n = {"roi_bbox": 0, "decoder": 0, "targets": 0}
+t0 = time.time()
+while time.time() - t0 < budget:
+    which = rng.integers(0, 3)
+    if which == 0:
+        G = int(rng.integers(3, 40))
+        N = G * G * 9
+        K = int(rng.integers(1, N + 1))
+        R = int(rng.integers(1, min(2 * K, 2200) + 1))
+        B = int(rng.integers(1, 4))
+        thr = float(rng.choice([0.3, 0.5, 0.7, 0.9]))
+        hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+        hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
+        anchors = oracle.generate_anchors(hp)
+        deltas, _ = synth.rpn_outputs(int(rng.integers(1 << 30)), B, G)
+        deltas = (deltas * rng.choice([1.0, 0.3, 0.05])).astype(np.float32)
+        scores = scores_like((B, G, G, 9)).astype(np.float32)
+        for name, val in (("FRCNN_PROPOSAL_THREADS", rng.choice([256, 1024])), ("FRCNN_PROPOSAL_CHUNK", rng.choice([64, 128, 256])),
+                          ("FRCNN_PROPOSAL_EXACT_SLICES", rng.integers(0, 2)), ("FRCNN_SORT_RADIX_ONLY", rng.integers(0, 2)),
+                          ("FRCNN_ROI_BBOX_BITMASK_MIN_R", rng.choice([0, 1, 512]))):
+            lib.set_schedule(name, int(val))
+        got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+        want = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], K, R, thr)
+        same(got, want, f"RoIBBox G={G} K={K} R={R} B={B} thr={thr}")
+        n["roi_bbox"] += 1
+    elif which == 1:
+        B, R, L = int(rng.integers(1, 4)), int(rng.integers(1, 500)), int(rng.integers(2, 40))
+        T = int(rng.integers(1, 300))
+        thr = float(rng.choice([0.0, 0.05, 0.3, 0.5, 0.8]))
+        rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+        if rng.random() < 0.3:
+            rois[:, R // 2:] = 0  # zero-padded RoIs
+        deltas = rng.normal(0, rng.choice([0.1, 0.5]), (B, R, L * 4)).astype(np.float32)
+        if rng.random() < 0.4:
+            probs = scores_like((B, R, L)).astype(np.float32)
+        else:
+            logits = rng.normal(0, 1, (B, R, L)) + 5 * np.eye(L)[rng.integers(0, L, (B, R))]
+            probs = (np.exp(logits) / np.exp(logits).sum(-1, keepdims=True)).astype(np.float32)
+        lib.set_schedule("FRCNN_DECODER_THREADS", int(rng.choice([256, 1024])))
+        hp = synth.hyper_params()
+        layer = pkg.faster_rcnn.Decoder(hp["variances"], L, max_total_size=T, score_threshold=thr)
+        got = layer([dev(rois), dev(deltas), dev(probs)])
+        want = oracle.decoder(rois, deltas, probs, hp["variances"], L, T, thr)
+        for g, w, name in zip(got, want, ("boxes", "labels", "scores")):
+            same(g, w, f"Decoder B={B} R={R} L={L} T={T} thr={thr} {name}")
+        n["decoder"] += 1
+    else:
+        B, G, M = int(rng.integers(1, 5)), int(rng.integers(2, 36)), int(rng.integers(1, 60))
+        hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+        hp.update(feature_map_shape=G, total_pos_bboxes=int(rng.integers(0, 300)), total_neg_bboxes=int(rng.integers(0, 300)))
+        anchors = oracle.generate_anchors(hp)
+        N = anchors.shape[0]
+        gt, labels = synth.gt_boxes(int(rng.integers(1 << 30)), B, M)
+        if rng.random() < 0.5:
+            k = min(M, 5)
+            gt[:, :k] = anchors[rng.integers(0, N, k)]
+            labels[:, :k] = 1
+        lo, hi = [(1, 4), (1, 2560), (3000, 4200), (-3, 60), (1, 2 ** 30)][int(rng.integers(0, 5))]
+        rp = rng.integers(lo, hi, (B, N)).astype(np.int32)
+        rn = rng.integers(lo, hi, (B, N)).astype(np.int32)
+        gd, gl = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp, random_masks=(dev(rp), dev(rn)))
+        wd, wl = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
+        same(gl, wl, f"rpn labels B={B} G={G} M={M} ints=[{lo},{hi})")
+        same(gd, wd, f"rpn deltas B={B} G={G} M={M}")
+        n["targets"] += 1
+print("ok", n, f"in {time.time() - t0:.0f} s", flush=True)
