@@ -53,7 +53,11 @@ def scores_like(shape):
 lib = pkg._lib
 n = {"roi_bbox": 0, "decoder": 0, "targets": 0}
 t0 = time.time()
+t_print = t0
 while time.time() - t0 < budget:
+    if time.time() - t_print > 30:  # a sign of life (a silent GPU job is taken to be hung)
+        t_print = time.time()
+        print(f"{t_print - t0:.0f} s", n, flush=True)
     which = rng.integers(0, 3)
     if which == 0:
         G = int(rng.integers(3, 40))
