@@ -1,4 +1,4 @@
-"""Randomised parity stress beyond the fixed-seed tests: RoIBBox / Decoder / RPN targets against the CPU oracle with fresh
+"""Randomised parity stress beyond the fixed-seed tests: RoIBBox / Decoder / RPN targets / RoIPooling / top_k / RoIDelta against the CPU oracle with fresh
 seeds, shapes and score distributions for a given number of seconds.  Test infrastructure (uses oracle/); prints the first
 mismatch and exits 1, or a summary.
 
@@ -51,14 +51,57 @@ def scores_like(shape):
 
 
 lib = pkg._lib
-n = {"roi_bbox": 0, "decoder": 0, "targets": 0}
+n = {"roi_bbox": 0, "decoder": 0, "targets": 0, "roi_pooling": 0, "top_k": 0, "roi_delta": 0}
 t0 = time.time()
 t_print = t0
 while time.time() - t0 < budget:
     if time.time() - t_print > 30:  # a sign of life (a silent GPU job is taken to be hung)
         t_print = time.time()
         print(f"{t_print - t0:.0f} s", n, flush=True)
-    which = rng.integers(0, 3)
+    which = rng.integers(0, 6)
+    if which == 3:
+        B = int(rng.integers(1, 5))
+        H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        C = int(rng.choice([1, 3, 4, 8, 36, 64, 100, 256, 576]))
+        R = int(rng.choice([1, 2, 7, 33, 64, 300, 700]))
+        ph, pw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        for name, val in (("FRCNN_CROP_SPLIT", rng.choice([-1, 0, 2, 4, 8])), ("FRCNN_CROP_SORT", rng.integers(0, 2)),
+                          ("FRCNN_CROP_PREFETCH", rng.choice([-1, 0, 7, 32, 640032])), ("FRCNN_CROP_SLICE", rng.choice([-1, 0, 1])),
+                          ("FRCNN_CROP_ROWS", rng.choice([-1, 0, 1]))):
+            lib.set_schedule(name, None if val < 0 else int(val))
+        fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
+        rois = rng.uniform(-0.2, 1.2, (B, R, 4)).astype(np.float32)
+        got = pkg.faster_rcnn.RoIPooling(synth.hyper_params(pooling_size=(ph, pw)))([dev(fm), dev(rois)])
+        same(got, oracle.roi_pooling(fm, rois, (ph, pw)), f"RoIPooling B={B} H={H} W={W} C={C} R={R} ({ph},{pw})")
+        n["roi_pooling"] += 1
+        continue
+    if which == 4:
+        B, N = int(rng.integers(1, 4)), int(rng.integers(1, 30000))
+        K = int(rng.integers(1, min(N, 12000) + 1))
+        sc = scores_like((B, N)).astype(np.float32)
+        lib.set_schedule("FRCNN_SORT_RADIX_ONLY", int(rng.integers(0, 2)))
+        vals, idx = pkg.bbox_utils.top_k(dev(sc), K)
+        wv, wi = oracle.top_k(sc, K)
+        same(idx, wi, f"top_k indices B={B} N={N} K={K}")
+        same(vals, wv, f"top_k values B={B} N={N} K={K}")
+        n["top_k"] += 1
+        continue
+    if which == 5:
+        B, R, M, L = int(rng.integers(1, 4)), int(rng.integers(1, 1500)), int(rng.integers(1, 40)), int(rng.integers(2, 30))
+        hp = pkg.train_utils.get_hyper_params("vgg16")
+        hp.update(total_labels=L, total_pos_bboxes=int(rng.integers(0, 200)), total_neg_bboxes=int(rng.integers(0, 200)))
+        gt, labels = synth.gt_boxes(int(rng.integers(1 << 30)), B, M, L)
+        rois = np.clip(gt[:, rng.integers(0, M, R)] + rng.normal(0, 0.05, (B, R, 4)), 0, 1).astype(np.float32)
+        rois[:, (3 * R) // 4:] = 0
+        lo, hi = [(1, 4), (1, 2000), (3900, 4300), (-3, 60), (1, 2 ** 30)][int(rng.integers(0, 5))]
+        rp = rng.integers(lo, hi, (B, R)).astype(np.int32)
+        rn = rng.integers(lo, hi, (B, R)).astype(np.int32)
+        gd, gl = pkg.faster_rcnn.RoIDelta(hp)([dev(rois), dev(gt), dev(labels)], random_masks=(dev(rp), dev(rn)))
+        wd, wl = oracle.roi_delta(rois, gt, labels, hp, (rp, rn))
+        same(gl, wl, f"RoIDelta labels B={B} R={R} M={M} L={L}")
+        same(gd, wd, f"RoIDelta deltas B={B} R={R} M={M} L={L}")
+        n["roi_delta"] += 1
+        continue
     if which == 0:
         G = int(rng.integers(3, 40))
         N = G * G * 9
