@@ -327,6 +327,9 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spin-up-ms", type=float, default=300.0,
+                    help="untimed steps of the same workload for this many milliseconds before the W warm-up steps (GPU clocks "
+                         "ramp up over tens of milliseconds of load; 0 = none)")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="override the config's (global / per-GPU) batch")
@@ -435,11 +438,24 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def run_blocks(step_fn, steps, warmup, blocks, every, pipe=None):
+    def run_blocks(step_fn, steps, warmup, blocks, every, pipe=None, spin_ms=0.0):
         """`blocks` timed blocks of `steps` steps.  Returns (per-block seconds [max over ranks], event pairs, host enqueue s/step)."""
         n_ev = blocks * ((steps + every - 1) // every) if every else 0
         evs = [(pkg._lib.HipEvent(timing_flags), pkg._lib.HipEvent(timing_flags)) for _ in range(n_ev)]
         used = []
+        # Device spin-up (untimed, BEFORE the W warm-up steps, disclosed as "spin_up_ms" in the JSON line): the same steps for
+        # a fixed wall time.  A fresh process finds the GPU in its idle power state and the clocks keep rising for some tens
+        # of milliseconds of load: with --steps 20 --warmup 5 the timed blocks of one run read 0.154, 0.164, 0.153, 0.149,
+        # 0.145, ... 0.136 ms per step, i.e. the first blocks measure the power management, not the kernels.
+        t_spin = time.perf_counter()
+        n_spin = 0
+        while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
+            for _ in range(16):
+                step_fn(n_spin, None)
+                n_spin += 1
+            if pipe is not None:
+                pipe.synchronize()
+            torch.cuda.synchronize()
         for i in range(warmup):
             step_fn(i, None)
         times, host = [], []
@@ -497,7 +513,8 @@ def main() -> int:
         step, every = step_pipeline, TIME_EVERY * group
     else:
         step, every = step_sequential, TIME_EVERY
-    times, samples, host_s = run_blocks(step, args.steps, args.warmup, args.blocks, every, pipe if mode == "pipeline" else None)
+    times, samples, host_s = run_blocks(step, args.steps, args.warmup, args.blocks, every, pipe if mode == "pipeline" else None,
+                                        spin_ms=args.spin_up_ms)
 
     launch_batches = group if mode == "pipeline" else 1  # batches one launch of the dominant kernel covers
     dom = stats(samples)
@@ -590,6 +607,7 @@ def main() -> int:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "spin_up_ms": args.spin_up_ms,
             "ms_per_step": round(med / args.steps * 1e3, 4),
             "blocks": {"n": args.blocks, "value_median": round(value, 1),
                        "value_min": round(b_global * args.steps / max(times), 1),

@@ -1,17 +1,19 @@
 #!/bin/bash
 # The round's evidence for bench.py, on the GPU box: the default bench line, one rocprofv3 kernel trace per schedule of the
 # SAME workload (cold rotating inputs), and separate FETCH_SIZE / WRITE_SIZE passes over the crop kernel in that state.
+# The bench runs with the driver's arguments (--steps 20 --warmup 5), so the files can be laid beside BENCH_rNN.json.
 # usage: tools/profile_bench.sh <tag>      -> gpurun_out/<tag>_*
 set -e
 tag=$1
+drv="--steps 20 --warmup 5"
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out
-timeout -k 10 600 python3 -u $root/bench.py > $out/${tag}_bench.json.log 2> $out/${tag}_bench.err
+timeout -k 10 600 python3 -u $root/bench.py $drv > $out/${tag}_bench.json.log 2> $out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
 for mode in pipeline sequential; do
   rm -rf $out/${tag}_trace_$mode
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace_$mode -o t -- \
-    python3 $root/bench.py --no-cpu-baseline --no-other-configs --no-other-schedule --mode $mode > $out/${tag}_bench_$mode.json.log 2> $out/${tag}_trace_$mode.err
+    python3 $root/bench.py $drv --no-cpu-baseline --no-other-configs --no-other-schedule --mode $mode > $out/${tag}_bench_$mode.json.log 2> $out/${tag}_trace_$mode.err
   cp $(find $out/${tag}_trace_$mode -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_${mode}_kernel_stats.csv
   rm -rf $out/${tag}_trace_$mode
 done
