@@ -177,6 +177,35 @@ def test_band_filter_never_contradicts_the_division(thr):
     assert (~(yes | no)).mean() < 0.5  # the band is narrow: most near-threshold pairs are still decided
 
 
+@pytest.mark.parametrize("thr", [0.7, 0.5, 0.3, 0.1, 0.65, 1e-3, 0.999, 0.25, 1.0, 1e-6, 37.5, 1e6])
+def test_union_free_band_filter_never_contradicts_the_division(thr):
+    """The packed form (nms_core.hpp, IouThr::k_hi / k_lo): with s = fl(area_i + area_j), inter > fl(s * k_hi) must imply
+    fl32(inter / fl(s - inter)) > thr and inter < fl(s * k_lo) the opposite; k = thr / (1 + thr) widened by 2^-21 in double
+    and rounded outwards, as make_iou_thr does."""
+    rng = np.random.default_rng(int(thr * 1000) + 7)
+    n = 2_000_000
+    thr = f32(thr)
+    k = float(thr) / (1.0 + float(thr))
+    k_hi = np.nextafter(f32(k * (1.0 + 2.0 ** -21)), f32(2.0))
+    k_lo = np.nextafter(f32(k * (1.0 - 2.0 ** -21)), f32(0.0))
+    s_ = (10.0 ** rng.uniform(-3, 1, n)).astype(f32)
+    inter = (s_.astype(np.float64) * k).astype(f32)
+    inter = (inter.view(np.int32) + rng.integers(-60, 61, n).astype(np.int32)).view(f32)  # +-60 ulp around the boundary
+    # an intersection never exceeds the smaller of the two areas (fp32 products are monotone), i.e. half their sum: for
+    # thresholds above 1 the boundary lies beyond that, and only the far side ("no") can be met
+    inter = np.minimum(inter, s_ * f32(0.5) * f32(1.0 + 2.0 ** -22))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = (inter / (s_ - inter)) > thr
+    yes = inter > s_ * k_hi
+    no = inter < s_ * k_lo
+    assert not (yes & ~ref).any() and not (no & ref).any()
+    assert not (yes & no).any()
+    if thr <= 1:
+        assert (~(yes | no)).mean() < 0.6  # the band is narrow: most near-threshold pairs are still decided
+    else:
+        assert no.all()
+
+
 # ---- the parallel-round resolve of a 64-candidate block (nms_core.hpp phase c, nms_bitmask.hip scan), restated ----------
 def _greedy_block(sup, alive):
     """Sequential greedy NMS inside a block: sup[r][c] = row r suppresses column c (r < c); alive = candidates not yet dead."""

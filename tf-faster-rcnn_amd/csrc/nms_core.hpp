@@ -18,15 +18,29 @@ static const int kMaxKept = 5000;  // kept-list capacity in LDS (28 B per entry)
 // boxes (non-finite coordinates, area outside [1e-30, 5e29]) or unusual thresholds (outside [1e-6, 1e6])
 // are re-evaluated with the reference formulation, division included (nms_iou_gt).  The fast and the
 // reference forms therefore agree on every input; tests/test_host.py checks the band logic on the CPU.
+// The PACKED form of the filter (nms_iou_gt_fast2: both boxes regular) goes one step further and never forms the union:
+// with s = fl(area_i + area_j), the sum the reference forms too, uni = fl(s - inter) and the real ratio r = inter / (s - inter),
+//   q = r * (1 + d2) / (1 + d1), |d1|, |d2| <= 2^-24,   and   r > thr  <=>  inter > s * k,  k = thr / (1 + thr);
+//   inter > s * k * (1 + e)  =>  r > thr * (1 + e) / (1 - thr * e) >= thr * (1 + e),   and likewise below.
+// With k_hi >= k * (1 + 2^-21) and k_lo <= k * (1 - 2^-21) (formed in double, rounded outwards), and one more 2^-24 for the
+// product fl(s * k_hi):  inter > fl(s * k_hi) => q > thr,   inter < fl(s * k_lo) => q <= thr  -- two multiplies per pair where
+// the form above needs a subtraction and three.  tests/test_host.py checks both forms against the division.
 struct IouThr {
   float thr;
   int slow_only;
+  float k_hi, k_lo;
 };
 
 static inline IouThr make_iou_thr(float thr) {
   IouThr t;
   t.thr = thr;
   t.slow_only = !(thr >= 1e-6f && thr <= 1e6f);
+  t.k_hi = t.k_lo = 0.0f;
+  if (!t.slow_only) {
+    const double k = (double)thr / (1.0 + (double)thr);
+    t.k_hi = nextafterf((float)(k * (1.0 + 4.76837158203125e-07)), 2.0f);
+    t.k_lo = nextafterf((float)(k * (1.0 - 4.76837158203125e-07)), 0.0f);
+  }
   return t;
 }
 
@@ -115,11 +129,11 @@ __device__ __forceinline__ bool nms_iou_gt_fast(const PBox &i, const PBox &j, co
 
 // The band filter for TWO row boxes (a, b) against one box `me`, all three REGULAR (finite, area in [1e-30, 5e29]: no
 // flags to look at), as packed fp32: the subtractions, products and scalings of the two tests share v_pk_add_f32 /
-// v_pk_mul_f32 (13 VALU instructions per pair instead of 19; only max / min have no packed form).  Same operations, same
-// roundings as nms_iou_gt_fast.  a_area2 = (area a, area b).
+// v_pk_mul_f32 (10 VALU instructions per pair instead of 19; only max / min have no packed form), in the union-free form
+// described at IouThr.  a_area2 = (area a, area b).
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void nms_iou_gt_fast2(const float4 &me, float me_area, const float4 &a, const float4 &b, v2f ab_area,
-                                                 float thr, bool &yes_a, bool &yes_b, bool &irr) {
+                                                 const IouThr &t, bool &yes_a, bool &yes_b, bool &irr) {
   v2f mny, mxy, mnx, mxx;
   mny.x = hw_min(me.z, a.z);
   mny.y = hw_min(me.z, b.z);
@@ -130,21 +144,19 @@ __device__ __forceinline__ void nms_iou_gt_fast2(const float4 &me, float me_area
   mxx.x = hw_max(me.y, a.y);
   mxx.y = hw_max(me.y, b.y);
   v2f ih = mny - mxy;
-  v2f iw = mnx - mxx;
+  const v2f iw = mnx - mxx;
   ih.x = hw_max(ih.x, 0.0f);
   ih.y = hw_max(ih.y, 0.0f);
-  iw.x = hw_max(iw.x, 0.0f);
-  iw.y = hw_max(iw.y, 0.0f);
+  // iw is NOT clamped at 0: with ih >= 0 a negative iw gives inter <= 0 (or -inf, or NaN from 0 * -inf), and the sum of two
+  // regular areas is > 0, so the pair comes out as "no" (inter < lo, lo > 0) -- which is what the clamped product 0 gives
+  // -- or, for the NaN, as undecided and goes to the exact test.
   const v2f inter = ih * iw;
   const v2f me2 = {me_area, me_area};
-  v2f uni = me2 + ab_area;
-  uni = uni - inter;
-  const v2f thr2 = {thr, thr};
-  const v2f tt = thr2 * uni;
-  const v2f c_hi = {1.000000476837158203125f, 1.000000476837158203125f};
-  const v2f c_lo = {0.999999523162841796875f, 0.999999523162841796875f};
-  const v2f hi = tt * c_hi;
-  const v2f lo = tt * c_lo;
+  const v2f sum = me2 + ab_area;
+  const v2f k_hi = {t.k_hi, t.k_hi};
+  const v2f k_lo = {t.k_lo, t.k_lo};
+  const v2f hi = sum * k_hi;
+  const v2f lo = sum * k_lo;
   yes_a = inter.x > hi.x;
   yes_b = inter.y > hi.y;
   const bool no_a = inter.x < lo.x, no_b = inter.y < lo.y;
@@ -219,34 +231,35 @@ __device__ __forceinline__ bool kept_list_hits(const KeptLds &K, const PBox &me,
   bool d = false;
   const int ngroups = (nk + 3) >> 2;
   if (all_regular) {
+    // No ballot and no branch inside the loop (the next group's LDS reads overlap this group's arithmetic).  The band filter
+    // never says "suppresses" wrongly, it can only leave a pair undecided: if that happened to a live lane anywhere in the
+    // wave's share, the share is gone through again with the reference formulation and OR-ed on top.
     const float4 meb = make_float4(me.ymin, me.xmin, me.ymax, me.xmax);
+    bool irr = false;
     for (int g4 = first; g4 < ngroups; g4 += step) {
       const float4 *kb = K.box + 4 * g4;
       const float4 b0 = kb[0], b1 = kb[1], b2 = kb[2], b3 = kb[3];
       const float4 ar = *reinterpret_cast<const float4 *>(K.area + 4 * g4);
       const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
-      bool y0, y1, y2, y3, irr = false;
-      nms_iou_gt_fast2(meb, me.area, b0, b1, a01, thr.thr, y0, y1, irr);
-      nms_iou_gt_fast2(meb, me.area, b2, b3, a23, thr.thr, y2, y3, irr);
-      bool dd = y0 | y1 | y2 | y3;
-      if (__builtin_expect(ballot64(irr && live) != 0ull, 0)) {  // inside the band: the reference formulation
-        const NBox men = to_nbox(me);
-        const float4 bb[4] = {b0, b1, b2, b3};
-        const float aa[4] = {ar.x, ar.y, ar.z, ar.w};
-        dd = false;
-#pragma unroll
+      bool y0, y1, y2, y3;
+      nms_iou_gt_fast2(meb, me.area, b0, b1, a01, thr, y0, y1, irr);
+      nms_iou_gt_fast2(meb, me.area, b2, b3, a23, thr, y2, y3, irr);
+      d = d | y0 | y1 | y2 | y3;
+    }
+    if (__builtin_expect(ballot64(irr && live) != 0ull, 0)) {
+      const NBox men = to_nbox(me);
+      for (int g4 = first; g4 < ngroups; g4 += step) {
         for (int u = 0; u < 4; ++u) {
+          const float4 bb = K.box[4 * g4 + u];
           NBox kn;
-          kn.ymin = bb[u].x;
-          kn.xmin = bb[u].y;
-          kn.ymax = bb[u].z;
-          kn.xmax = bb[u].w;
-          kn.area = aa[u];
-          dd = dd | nms_iou_gt(men, kn, thr.thr);
+          kn.ymin = bb.x;
+          kn.xmin = bb.y;
+          kn.ymax = bb.z;
+          kn.xmax = bb.w;
+          kn.area = K.area[4 * g4 + u];
+          d = d | nms_iou_gt(men, kn, thr.thr);
         }
       }
-      d = d | dd;
-      if (ballot64(live && !d) == 0ull) break;
     }
   } else {
     for (int g4 = first; g4 < ngroups; g4 += step) {
@@ -278,8 +291,8 @@ __device__ __forceinline__ uint32_t tile_rows4(const float4 *box, const float *a
     const float4 ar = *reinterpret_cast<const float4 *>(area + irow0);
     const v2f a01 = {ar.x, ar.y}, a23 = {ar.z, ar.w};
     bool irr = false;
-    nms_iou_gt_fast2(meb, me.area, r0, r1, a01, thr.thr, bit[0], bit[1], irr);
-    nms_iou_gt_fast2(meb, me.area, r2, r3, a23, thr.thr, bit[2], bit[3], irr);
+    nms_iou_gt_fast2(meb, me.area, r0, r1, a01, thr, bit[0], bit[1], irr);
+    nms_iou_gt_fast2(meb, me.area, r2, r3, a23, thr, bit[2], bit[3], irr);
     if (__builtin_expect(ballot64(irr) != 0ull, 0)) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) bit[u] = nms_iou_gt(to_nbox(load_pbox(box, area, flag, irow0 + u)), to_nbox(me), thr.thr);
