@@ -476,6 +476,52 @@ def test_roi_bbox_dense_suppression(pkg):
     assert_bits(got, want, "RoIBBox dense")
 
 
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 0.9])
+def test_roi_bbox_pairs_at_the_iou_threshold(pkg, thr):
+    """Pairs whose IoU lies within a few ulps of the threshold, on both routes of the packed band filter (nms_core.hpp,
+    union-free form): 64 partners that meet their box in the KEPT LIST (candidates 64..127 against 0..63) and 48 pairs
+    inside one chunk's tile.  Equal-size boxes shifted by dx have IoU (w - dx) / (w + dx); dx = w (1 - thr) / (1 + thr) in
+    double, then the fp32 roundings of the decode scatter the IoUs around thr.  Any pair the filter decides wrongly flips a
+    keep / suppress and shows as a mismatch with the oracle."""
+    G = 5
+    N = G * G * 9  # 225 "anchors": the boxes themselves (zero deltas)
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    hp.update(feature_map_shape=G, pre_nms_topn=N, test_nms_topn=N, nms_iou_threshold=thr)
+    rng = np.random.default_rng(int(thr * 100))
+    inside = near = 0
+    for rep in range(24):
+        cells = rng.permutation(144)[:112]  # 12 x 12 cells of 1/12: no overlap between cells
+        cy, cx = (cells // 12) / 12.0, (cells % 12) / 12.0
+        h = rng.uniform(0.02, 0.07, 112)
+        w = rng.uniform(0.015, 0.035, 112)
+        y1, x1 = cy + rng.uniform(0.0, 0.005, 112), cx + rng.uniform(0.0, 0.005, 112)
+        dx = w * (1.0 - thr) / (1.0 + thr) * (1.0 + rng.integers(-8, 9, 112) * 2.0 ** -23)
+        base = np.stack([y1, x1, y1 + h, x1 + w], -1)
+        partner = np.stack([y1, x1 + dx, y1 + h, x1 + dx + w], -1)
+        boxes = np.zeros((N, 4), np.float64)
+        boxes[0:64] = base[:64]
+        boxes[64:128] = partner[:64]
+        boxes[128:224:2] = base[64:]
+        boxes[129:224:2] = partner[64:]
+        boxes[224] = [0.99, 0.99, 0.995, 0.995]
+        anchors = boxes.astype(np.float32)
+        deltas = np.zeros((1, G, G, 36), np.float32)
+        scores = np.linspace(0.99, 0.01, N).astype(np.float32).reshape(1, G, G, 9)
+        got = pkg.faster_rcnn.RoIBBox(dev(anchors), "inference", hp)([dev(deltas), dev(scores)])
+        want, _, valid = oracle.roi_bbox(deltas, scores, anchors, hp["variances"], N, N, thr, return_all=True)
+        assert_bits(got, want, f"RoIBBox threshold pairs thr={thr} rep={rep}")
+        # how close the cases really are (fp32 boxes as the kernel sees them, IoU in double)
+        a, b = anchors[0:64].astype(np.float64), anchors[64:128].astype(np.float64)
+        iw = np.minimum(a[:, 3], b[:, 3]) - np.maximum(a[:, 1], b[:, 1])
+        inter = iw * (a[:, 2] - a[:, 0])
+        iou = inter / ((a[:, 3] - a[:, 1]) * (a[:, 2] - a[:, 0]) + (b[:, 3] - b[:, 1]) * (b[:, 2] - b[:, 0]) - inter)
+        inside += int((np.abs(iou / thr - 1.0) < 2.0 ** -21).sum())
+        near += int((np.abs(iou / thr - 1.0) < 2.0 ** -17).sum())
+        assert 0 < int(valid[0]) < N
+    assert near >= 24 * 32, near  # the construction does put the pairs at the threshold ...
+    assert inside > 0, inside     # ... and some inside the filter's band (they take the exact test)
+
+
 def test_roi_bbox_more_anchors_than_the_key_cache_and_member_masks_hold(pkg, knobs):
     """N = 72,900 anchors: no LDS key cache in any form and more elements per thread than the fast slices' 64-bit member
     masks cover, so the fused kernel runs on exact-rank slices with keys from global memory."""
