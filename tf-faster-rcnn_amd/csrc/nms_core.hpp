@@ -582,9 +582,19 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
     FRCNN_STAMP(11);
     if (w == 0) {
       // ---- c. greedy resolve of the chunk in parallel rounds (see nms_chunk_resolve) ---------------------------------
-      const unsigned long long deadw = uniform64(T.dead[c & 1]);
+      // Everything the resolve reads from LDS is requested at once, ahead of the rounds -- the dead word, the column
+      // word, and the lane's own candidate in case it is kept (the compiler would otherwise wait for each in turn, five
+      // round trips: it cannot tell that the kept list and the slice arrays do not overlap).
+      const int j = cbase + lane;
+      unsigned long long deadv = T.dead[c & 1];
+      unsigned long long col = T.colw[(c & 1) * 64 + lane];
+      unsigned long long regv = sreg[c];
+      float4 cb = sbox[j];
+      float ca = sarea[j];
+      int cf = sflag[j], ci = sidx[j];
+      asm volatile("" : "+v"(deadv), "+v"(col), "+v"(regv), "+v"(cb.x), "+v"(cb.y), "+v"(cb.z), "+v"(cb.w), "+v"(ca), "+v"(cf), "+v"(ci));
+      const unsigned long long deadw = uniform64(deadv);
       const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
-      const unsigned long long col = T.colw[(c & 1) * 64 + lane];
       unsigned long long und = ~deadw & valid;
       unsigned long long keptbits = 0ull;
       while (und != 0ull) {
@@ -607,11 +617,10 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
       }
       if ((keptbits >> lane) & 1ull) {
         const int pos = cnt + __popcll(keptbits & lanemask_lt());
-        const int j = cbase + lane;
-        K.box[pos] = sbox[j];
-        K.area[pos] = sarea[j];
-        K.flag[pos] = sflag[j];
-        K.idx[pos] = sidx[j];
+        K.box[pos] = cb;
+        K.area[pos] = ca;
+        K.flag[pos] = cf;
+        K.idx[pos] = ci;
       }
       cnt += __popcll(keptbits);
       if (lane < 4 && cnt + lane < ((cnt + 3) & ~3)) {  // null boxes up to the next multiple of 4
@@ -621,7 +630,7 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
       }
       if (lane == 0) {
         T.s_nk[0] = cnt;
-        if ((keptbits & ~uniform64(sreg[c])) != 0ull) T.s_nk[1] = 0;
+        if ((keptbits & ~uniform64(regv)) != 0ull) T.s_nk[1] = 0;
         if (c + 1 < nchunks) T.dead[(c + 1) & 1] = sbad[c + 1];
       }
       FRCNN_STAMP(14);
