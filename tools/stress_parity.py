@@ -1,4 +1,4 @@
-"""Randomised parity stress beyond the fixed-seed tests: RoIBBox / Decoder / RPN targets / RoIPooling / top_k / RoIDelta against the CPU oracle with fresh
+"""Randomised parity stress beyond the fixed-seed tests: RoIBBox / Decoder / RPN targets / RoIPooling / top_k / RoIDelta / combined NMS against the CPU oracle with fresh
 seeds, shapes and score distributions for a given number of seconds.  Test infrastructure (uses oracle/); prints the first
 mismatch and exits 1, or a summary.
 
@@ -51,14 +51,38 @@ def scores_like(shape):
 
 
 lib = pkg._lib
-n = {"roi_bbox": 0, "decoder": 0, "targets": 0, "roi_pooling": 0, "top_k": 0, "roi_delta": 0}
+n = {"roi_bbox": 0, "decoder": 0, "targets": 0, "roi_pooling": 0, "top_k": 0, "roi_delta": 0, "combined_nms": 0}
 t0 = time.time()
 t_print = t0
 while time.time() - t0 < budget:
     if time.time() - t_print > 30:  # a sign of life (a silent GPU job is taken to be hung)
         t_print = time.time()
         print(f"{t_print - t0:.0f} s", n, flush=True)
-    which = rng.integers(0, 6)
+    which = rng.integers(0, 7)
+    if which == 6:
+        B, nb = int(rng.integers(1, 4)), int(rng.integers(1, 900))
+        c = int(rng.integers(1, 6))
+        q = int(rng.choice([1, c]))
+        mpc, mt = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        iou = float(rng.choice([0.3, 0.5, 0.7, 0.9, 0.05, 0.999, 1.0, 1.5, 1e-5, 0.0, 2e6]))
+        sthr = float(rng.choice([float("-inf"), 0.0, 0.3, 0.6]))
+        ctr = rng.random((B, nb, q, 2))
+        hw = rng.uniform(0.01, float(rng.choice([0.05, 0.25, 0.6])), (B, nb, q, 2))
+        boxes = np.concatenate([ctr - hw, ctr + hw], -1).astype(np.float32)
+        if rng.random() < 0.3:
+            boxes[:, : nb // 3] = boxes[:, nb // 3: 2 * (nb // 3)]  # exact duplicates
+        if rng.random() < 0.2:
+            boxes[:, ::7, :, 2:] = boxes[:, ::7, :, :2]  # zero-area boxes
+        if rng.random() < 0.2:
+            boxes[:, ::5] = boxes[:, ::5, :, [2, 3, 0, 1]]  # corners the other way round
+        sc = scores_like((B, nb, c)).astype(np.float32)
+        got = pkg.bbox_utils.non_max_suppression(dev(boxes), dev(sc), max_output_size_per_class=mpc, max_total_size=mt,
+                                                iou_threshold=iou, score_threshold=sthr)
+        want = oracle.combined_non_max_suppression(boxes, sc, mpc, mt, iou, sthr)
+        for g, w_, name in zip(got, want, ("boxes", "scores", "classes", "valid")):
+            same(g, w_, f"combined NMS B={B} n={nb} q={q} c={c} mpc={mpc} mt={mt} iou={iou} thr={sthr} {name}")
+        n["combined_nms"] += 1
+        continue
     if which == 3:
         B = int(rng.integers(1, 5))
         H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
@@ -108,7 +132,7 @@ while time.time() - t0 < budget:
         K = int(rng.integers(1, N + 1))
         R = int(rng.integers(1, min(2 * K, 2200) + 1))
         B = int(rng.integers(1, 4))
-        thr = float(rng.choice([0.3, 0.5, 0.7, 0.9]))
+        thr = float(rng.choice([0.3, 0.5, 0.7, 0.9, 0.05, 0.999, 1.0, 1.5, 1e-5]))
         hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
         hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
         anchors = oracle.generate_anchors(hp)
