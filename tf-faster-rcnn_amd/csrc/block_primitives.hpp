@@ -145,9 +145,11 @@ __device__ __forceinline__ void radix_select(KeyF keyf, int n, int need, uint32_
 // P = 0xFFFF and cnt_le = their number).  low_byte = the smallest top byte any valid key has (0 when there is none):
 // low_byte << 24 bounds every valid key from below.  One 256-bin histogram shared by the waves (the top byte through
 // wave-aggregated adds), three barriers per pass.  hist: 256 uint32 of LDS, misc: >= 5 ints.
+// have_pass1 (workgroup-uniform): the caller has already put the top-byte histogram of the valid keys into hist[0..255]
+// (complete before the call: the function starts with a barrier), so the first pass only has to read it.
 template <int NT = kNT, class KeyF>
 __device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint32_t *hist, int *misc, uint32_t &P,
-                                                int &cnt_le, bool &all, uint32_t &low_byte) {
+                                                int &cnt_le, bool &all, uint32_t &low_byte, bool have_pass1 = false) {
   constexpr int kNT = NT;
   static_assert(NT >= 256 && NT % 64 == 0, "prefix16_select: the 256 bins are cleared by the first 256 threads");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -159,22 +161,24 @@ __device__ __forceinline__ void prefix16_select(KeyF keyf, int n, int need, uint
   cnt_le = 0;
   for (int pass = 1; pass >= 0; --pass) {
     const int shift = 16 + pass * 8;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    if (pass == 1) {
-      const int n_up = (n + kNT - 1) / kNT * kNT;  // uniform trip count for the ballots
-      for (int i = tid; i < n_up; i += kNT) {
-        uint32_t k = 0;
-        const bool v = (i < n) && keyf(i, k);
-        hist_add(hist, (k >> shift) & 255u, v);
+    if (!(pass == 1 && have_pass1)) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      if (pass == 1) {
+        const int n_up = (n + kNT - 1) / kNT * kNT;  // uniform trip count for the ballots
+        for (int i = tid; i < n_up; i += kNT) {
+          uint32_t k = 0;
+          const bool v = (i < n) && keyf(i, k);
+          hist_add(hist, (k >> shift) & 255u, v);
+        }
+      } else {
+        for (int i = tid; i < n; i += kNT) {
+          uint32_t k = 0;
+          if (keyf(i, k) && (k >> 24) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
       }
-    } else {
-      for (int i = tid; i < n; i += kNT) {
-        uint32_t k = 0;
-        if (keyf(i, k) && (k >> 24) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-      }
+      __syncthreads();
     }
-    __syncthreads();
     if (w == 0) {
       const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
       const uint32_t s4 = h0 + h1 + h2 + h3;

@@ -105,15 +105,25 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
 
   FRCNN_STAMP(0);
   if (tid == 0) misc[9] = 0;  // misc[9] = a bucket of the fast slice sort overflowed
+  // The first fast slice's boundary search starts with a histogram of the top key byte over every 8th key: those keys pass
+  // through this thread's registers while the key cache is filled, so the histogram is taken here (LDS adds by one lane in
+  // eight) and prefix16_select's first pass finds it ready -- two barriers and one sweep less.
+  const bool hist_in_fill = cache_keys != 0 && fast_slices != 0 && N <= 64 * kNT && (kNT % 8) == 0;
   if (cache_keys) {
     // eight loads per thread in flight (the compiler unrolls this loop by two and waits for every pair: with inputs that
-    // come from HBM, not L2, that is 2 us per pair).  cache_keys == 2: N beyond what LDS holds as 32-bit keys (config 5:
-    // 35721) -- the fast slices decide membership from the upper 16 bits alone, so those are what is cached; the full key
-    // is fetched for the members of a slice only.
-    for (int i0 = tid; i0 < N; i0 += 8 * kNT) {
-      float sc[8];
+    // come from HBM, not L2, that is 2 us per pair); the first eight are requested BEFORE the histogram's bins are cleared
+    // and the barrier behind that (a barrier waits for LDS only: the loads stay in flight across it).  cache_keys == 2: N
+    // beyond what LDS holds as 32-bit keys (config 5: 35721) -- the fast slices decide membership from the upper 16 bits
+    // alone, so those are what is cached; the full key is fetched for the members of a slice only.
+    float sc[8];
+    int i0 = tid;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) sc[u] = (i0 + u * kNT < N) ? scores[i0 + u * kNT] : 0.0f;
+    for (int u = 0; u < 8; ++u) sc[u] = (i0 + u * kNT < N) ? scores[i0 + u * kNT] : 0.0f;
+    if (hist_in_fill) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+    }
+    while (i0 < N) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = i0 + u * kNT;
@@ -123,7 +133,13 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
             kcache[i] = k;
           else
             kc16[i] = (uint16_t)(k >> 16);
+          if (hist_in_fill && (tid & 7) == 0) atomicAdd(&hist[k >> 24], 1u);  // (i & 7 == tid & 7: NT is a multiple of 8)
         }
+      }
+      i0 += 8 * kNT;
+      if (i0 < N) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sc[u] = (i0 + u * kNT < N) ? scores[i0 + u * kNT] : 0.0f;
       }
     }
   }
@@ -179,7 +195,8 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
       int cnt_s;
       bool allp;
       const int target = (s_now * 11) >> 4;
-      prefix16_select<NT>(key_sample, (N + 7) >> 3, (target >> 3) > 0 ? (target >> 3) : 1, hist, misc, P, cnt_s, allp, low_byte);
+      prefix16_select<NT>(key_sample, (N + 7) >> 3, (target >> 3) > 0 ? (target >> 3) : 1, hist, misc, P, cnt_s, allp, low_byte,
+                          hist_in_fill && consumed == 0);
       const uint32_t hi16 = allp ? 0xFFFFu : P;
       const uint32_t hi = (hi16 << 16) | 0xFFFFu;
       // One sweep over the upper key halves: every thread notes which of its (strided) elements the cut holds as bits of a
