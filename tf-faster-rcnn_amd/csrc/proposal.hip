@@ -43,6 +43,8 @@ struct ProposalParams {
   float score_thr;  // -inf: combined_non_max_suppression's default, strict '>'
 };
 
+static const int kDecodedIsNormalised = 1 << 30;  // flag bit in a candidate's element-index word (N is far below 2^30)
+
 template <int CH, int NT>
 static inline size_t proposal_lds_bytes(int Rc, int S) {
   return round_up(nms_lds_bytes<CH>(Rc), 16) + (size_t)S * (4 + 4 + 2 + 2) + (size_t)(NT / 64) * 256 * 4 + 64 * 4 +
@@ -489,6 +491,12 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
           bad = !(scores[ei] > p.score_thr);
           nb = normalise_box(box);
           fl = box_flags(box, nb);
+          // bit 30 of the index word: the corner-normalised box IS the decoded box, bit for bit (always, unless an anchor
+          // has a negative extent or a coordinate is NaN) -- the output pass then takes a kept box from LDS instead of
+          // fetching anchor and deltas and decoding it a second time
+          const bool same_bits = __float_as_int(nb.ymin) == __float_as_int(box.x) && __float_as_int(nb.xmin) == __float_as_int(box.y) &&
+                                 __float_as_int(nb.ymax) == __float_as_int(box.z) && __float_as_int(nb.xmax) == __float_as_int(box.w);
+          ei |= same_bits ? kDecodedIsNormalised : 0;
         }
         sbox[j] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
         sarea[j] = nb.area;
@@ -536,13 +544,14 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
     float sc = 0.0f;
     if (r < nk) {
-      const int ei = L.k_idx[r];
-      o = box_of(ei);
+      const int ew = L.k_idx[r];
+      const int ei = ew & (kDecodedIsNormalised - 1);
+      o = (ew & kDecodedIsNormalised) ? L.k_box[r] : box_of(ei);
       o.x = clip01(o.x);
       o.y = clip01(o.y);
       o.z = clip01(o.z);
       o.w = clip01(o.w);
-      sc = scores[ei];
+      if (io.out_scores) sc = scores[ei];
     }
     *reinterpret_cast<float4 *>(io.out_boxes + ((long long)b * R + r) * 4) = o;
     if (io.out_scores) io.out_scores[(long long)b * R + r] = sc;
@@ -578,6 +587,7 @@ int launch_proposal(const float *const *deltas, const float *const *scores, int 
   // R_out rows are written; at most R_nms = min(R_out, K) boxes can be kept.
   if (R_nms != R_out) return FRCNN_OK;  // zero rows beyond K candidates: leave to the generic path
   if (R_nms > kMaxKept) return FRCNN_OK;
+  if (N >= kDecodedIsNormalised) return FRCNN_OK;  // (bit 30 of an element index is a flag inside the kernel)
   if (groups < 1 || groups > kProposalGroups) return FRCNN_OK;
   int Rc = (R_nms + 7) & ~7;
   if (Rc < 8) Rc = 8;
