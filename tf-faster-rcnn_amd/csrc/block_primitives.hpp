@@ -14,13 +14,14 @@ static const int kNT = 1024;
 static const int kNW = 16;
 
 // Exclusive scan of one int per thread; `total` is returned to every thread.  wsum: kNW ints of LDS.
-template <int NT = kNT>
+// LEAD_BARRIER = false: the caller vouches that every thread has passed a barrier since wsum was last read.
+template <int NT = kNT, bool LEAD_BARRIER = true>
 __device__ __forceinline__ int block_excl_scan(int v, int *wsum, int &total) {
   constexpr int kNW = NT / 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   int inc = v;
   inc = wave_incl_scan(inc);
-  __syncthreads();  // wsum may still be read from a previous call
+  if (LEAD_BARRIER) __syncthreads();  // wsum may still be read from a previous call
   if (lane == 63) wsum[w] = inc;
   __syncthreads();
   int base = 0, tot = 0;

@@ -220,7 +220,7 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
       else
         members_from([&](int i) -> uint32_t { return ~f_order_key(scores[i]) >> 16; });
       int Vf;
-      const int base = block_excl_scan<NT>(__popcll(mine), wsum, Vf);
+      const int base = block_excl_scan<NT, false>(__popcll(mine), wsum, Vf);  // (prefix16_select's barriers lie behind wsum's last reader)
       FRCNN_STAMP(2);
       if (Vf > s_now || Vf < 1) {
         fast = false;
@@ -256,7 +256,7 @@ void proposal_kernel(ProposalParams p, int Rc, int S, int cache_keys, int fast_s
         {
           const uint32_t a0 = hist[4 * tid], a1 = hist[4 * tid + 1], a2 = hist[4 * tid + 2], a3 = hist[4 * tid + 3];
           int total;
-          const int ex = block_excl_scan<NT>((int)(a0 + a1 + a2 + a3), wsum, total);
+          const int ex = block_excl_scan<NT, false>((int)(a0 + a1 + a2 + a3), wsum, total);  // (two barriers since the scan above)
           hist[4 * tid] = (uint32_t)ex;
           hist[4 * tid + 1] = (uint32_t)ex + a0;
           hist[4 * tid + 2] = (uint32_t)ex + a0 + a1;
