@@ -110,6 +110,7 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
 
   FRCNN_STAMP(20);
   for (int i = tid; i < 3 * (kDecMaxClasses + 4); i += kNT) ccount[i] = 0;  // ccount, cstart, kcount are contiguous
+  for (int i = tid; i < capV; i += kNT) hist[i] = 0u;  // the small-V schedule's rank accumulators (untouched until then)
   // The image's class probabilities are staged once, coalesced, in the (not yet used) sort buffer: phase A reads every row
   // twice, and a lane walking its own 84-byte row straight from memory pays two uncoalesced round trips.
   float *sprob = reinterpret_cast<float *>(perm);  // [R*L] <= 4*Vcap bytes
@@ -163,7 +164,7 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
     }
   }
   int V;
-  int pos = block_excl_scan<NT>(cnt, wsum, V);
+  int pos = block_excl_scan<NT, false>(cnt, wsum, V);  // (wsum has not been used yet)
   // class segment starts: exclusive prefix of ccount (wave 0, 4 classes per lane; the adds above are behind the scan's barriers)
   if (w == 0) {
     const int c0 = ccount[4 * lane], c1 = ccount[4 * lane + 1], c2 = ccount[4 * lane + 2], c3 = ccount[4 * lane + 3];
@@ -218,8 +219,7 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
     const int parts = Vp > 0 ? kNT / Vp : 1;  // >= 1 (V <= capV <= NT)
     const int part = Vp > 0 ? tid / Vp : 0;
     const int q = tid - part * Vp;  // position in cseg
-    for (int i = tid; i < V; i += kNT) racc[i] = 0u;
-    __syncthreads();
+    // (racc was cleared at the kernel's start: barriers lie between)
     int slot = 0, cls = 0, s0 = 0;
     if (part < parts && q < V) {
       slot = (int)cseg[q];
