@@ -148,10 +148,42 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
   const int E = (RL + kNT - 1) / kNT;
   const int e0 = tid * E;
   const int e1 = (e0 + E < RL) ? (e0 + E) : RL;
+  // Runs of up to kRun elements (config 2: 7) are read ONCE, all loads in flight together, and stay in registers across the
+  // scan: which of them are candidates is a bit mask, class and RoI of element u follow from the run's start by counting.
+  constexpr int kRun = 8;
+  const bool in_regs = E <= kRun;  // workgroup-uniform
+  float rv[kRun];
+  uint32_t cand = 0u;  // bit u: element e0 + u is a candidate
   int cnt = 0;
-  {
-    int r = (e0 < RL) ? e0 / L : 0;
-    int l = e0 - r * L;
+  const int r_first = (e0 < RL) ? e0 / L : 0;
+  const int l_first = (e0 < RL) ? e0 - r_first * L : 0;
+  if (in_regs) {
+    bool fg[kRun];
+    {
+      int r = r_first, l = l_first;
+#pragma unroll
+      for (int u = 0; u < kRun; ++u) {
+        const bool in = e0 + u < e1;
+        rv[u] = in ? sprob[e0 + u] : 0.0f;
+        fg[u] = in && (roi_fg[in ? r : 0] != 0);
+        const bool wrap = (l + 1 == L);
+        l = wrap ? 0 : l + 1;
+        r += wrap ? 1 : 0;
+      }
+    }
+    {
+      int l = l_first;
+#pragma unroll
+      for (int u = 0; u < kRun; ++u) {
+        const bool c = fg[u] && (rv[u] > p.score_thr);
+        cand |= c ? (1u << u) : 0u;
+        if (c) atomicAdd(&ccount[l], 1);
+        l = (l + 1 == L) ? 0 : l + 1;
+      }
+    }
+    cnt = __popc(cand);
+  } else {
+    int r = r_first, l = l_first;
     for (int e = e0; e < e1; ++e) {
       if ((roi_fg[r] != 0) && (sprob[e] > p.score_thr)) {
         ++cnt;
@@ -185,19 +217,33 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
   int *cfill = kcount;  // [L] segment fill counters (the NMS overwrites every class's entry)
   __syncthreads();
   if (cnt) {
-    int r = e0 / L;
-    int l = e0 - r * L;
-    for (int e = e0; e < e1; ++e) {
-      const float v = sprob[e];
-      if (roi_fg[r] != 0 && v > p.score_thr && pos < Vcap) {
-        key[pos] = ~f_order_key(v);
-        pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
-        if (small) cseg[cstart[l] + atomicAdd(&cfill[l], 1)] = (uint16_t)pos;
-        ++pos;
+    int r = r_first, l = l_first;
+    if (in_regs) {
+#pragma unroll
+      for (int u = 0; u < kRun; ++u) {
+        if (((cand >> u) & 1u) && pos < Vcap) {
+          key[pos] = ~f_order_key(rv[u]);
+          pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
+          if (small) cseg[cstart[l] + atomicAdd(&cfill[l], 1)] = (uint16_t)pos;
+          ++pos;
+        }
+        const bool wrap = (l + 1 == L);
+        l = wrap ? 0 : l + 1;
+        r += wrap ? 1 : 0;
       }
-      if (++l == L) {
-        l = 0;
-        ++r;
+    } else {
+      for (int e = e0; e < e1; ++e) {
+        const float v = sprob[e];
+        if (roi_fg[r] != 0 && v > p.score_thr && pos < Vcap) {
+          key[pos] = ~f_order_key(v);
+          pk[pos] = ((uint32_t)l << 24) | (uint32_t)r;
+          if (small) cseg[cstart[l] + atomicAdd(&cfill[l], 1)] = (uint16_t)pos;
+          ++pos;
+        }
+        if (++l == L) {
+          l = 0;
+          ++r;
+        }
       }
     }
   }

@@ -18,6 +18,21 @@ import tf_faster_rcnn_amd as pkg
 lib = pkg._lib.lib()
 lib.frcnn_debug_stamps.restype = ctypes.c_int
 lib.frcnn_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+if len(sys.argv) >= 2 and sys.argv[1] == "decoder":  # python tools/diag_stamps.py decoder  -> the Decoder kernel's stamps (cfg2)
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    rois_np = np.sort(np.random.default_rng(0).random((16, 300, 2, 2)).astype(np.float32), axis=2).reshape(16, 300, 4)
+    dl, pr = synth.head_outputs(0, 16, 300, 21)
+    dec = pkg.faster_rcnn.Decoder(hp["variances"], 21)
+    args = [torch.as_tensor(rois_np).cuda(), torch.as_tensor(dl).cuda(), torch.as_tensor(pr).cuda()]
+    buf = np.zeros(256, dtype=np.int64)
+    for it in range(3):
+        dec(args)
+        torch.cuda.synchronize()
+        n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+    for i in range(n):
+        print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
+    sys.exit(0)
 # optional: G K R on the command line (default BASELINE config 2: 32 6000 300; config 5: 63 12000 300)
 G_, K_, R_ = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 6000, 300)
 hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G_, pre_nms_topn=K_, test_nms_topn=R_)
