@@ -267,9 +267,16 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
     const int q = tid - part * Vp;  // position in cseg
     // (racc was cleared at the kernel's start: barriers lie between)
     int slot = 0, cls = 0, s0 = 0;
+    float4 roi4 = make_float4(0.f, 0.f, 0.f, 0.f), del4 = roi4;  // the candidate's RoI and deltas (part 0's threads)
     if (part < parts && q < V) {
       slot = (int)cseg[q];
-      cls = (int)(pk[slot] >> 24);
+      const uint32_t pw = pk[slot];
+      cls = (int)(pw >> 24);
+      if (part == 0) {  // requested here, used behind the barrier: the ranking hides the global-memory latency
+        const int r = (int)(pw & 0xFFFFFFu);
+        roi4 = rois[r];
+        del4 = deltas[(long long)r * L + cls];
+      }
       s0 = cstart[cls];
       const int m = ccount[cls];
       const uint32_t mykey = key[slot];
@@ -287,7 +294,7 @@ void decoder_kernel(DecoderParams p, int Vcap, int Rpc4, int nms_waves, int capV
     if (part == 0 && q < V) {
       const int qq = s0 + (int)racc[q];
       racc[q] = 0u;  // (own entry; reused by the cross-class ranking)
-      const float4 box = box_of((int)(pk[slot] & 0xFFFFFFu), cls);
+      const float4 box = decode_box(roi4, scale_deltas(del4, p.v0, p.v1, p.v2, p.v3));
       const NBox nb = normalise_box(box);
       snorm[qq] = make_float4(nb.ymin, nb.xmin, nb.ymax, nb.xmax);
       sorig[qq] = box;
