@@ -241,16 +241,7 @@ __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int
       // it).  The lowest undecided candidate always falls in one of the two classes, so every round makes progress; the
       // fixed point is the sequential greedy result, reached in (longest suppression chain) rounds -- a handful.
       const unsigned long long col = s_diag[(cb - cb0) * 64 + lane];
-      unsigned long long und = uniform64(~removed[cb]);
-      unsigned long long keptbits = 0ull;
-      while (und != 0ull) {
-        const bool in1 = (und >> lane) & 1ull;
-        und &= ~ballot64(in1 && (col & keptbits) != 0ull);
-        const bool in2 = (und >> lane) & 1ull;
-        const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
-        keptbits |= k;
-        und &= ~k;
-      }
+      unsigned long long keptbits = resolve_rounds(col, uniform64(~removed[cb]));
       int cnt = nk + __popcll(keptbits);
       if (cnt > R) {  // the greedy scan stops at R: keep the first R - nk of the block's kept candidates
         unsigned long long t = 0ull, bb = keptbits;

@@ -217,6 +217,26 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// The greedy order inside a block of 64 candidates, in parallel rounds: col = the earlier rows of the block that suppress
+// this lane's candidate, und0 (wave-uniform) = the candidates not yet decided.  A candidate hit by a KEPT row is removed, a
+// candidate none of whose still-undecided earlier rows suppresses it is kept; the lowest undecided candidate always falls in
+// one of the two classes, so every round makes progress and the fixed point is the sequential greedy result.  Returns the
+// kept candidates (wave-uniform).  The undecided / kept sets live in scalar registers: a lane only ANDs them with its
+// column word, and whether the lane itself is still undecided is applied to the ballots, not to the lanes.
+__device__ __forceinline__ unsigned long long resolve_rounds(unsigned long long col, unsigned long long und0) {
+  const uint32_t col_lo = (uint32_t)col, col_hi = (uint32_t)(col >> 32);
+  unsigned long long und = und0, keptbits = 0ull;
+  while (und != 0ull) {
+    const bool hit = ((col_lo & (uint32_t)keptbits) | (col_hi & (uint32_t)(keptbits >> 32))) != 0u;
+    und &= ~ballot64(hit);
+    const bool blocked = ((col_lo & (uint32_t)und) | (col_hi & (uint32_t)(und >> 32))) != 0u;
+    const unsigned long long k = und & ~ballot64(blocked);
+    keptbits |= k;
+    und &= ~k;
+  }
+  return keptbits;
+}
+
 // ---- pair-test helpers shared by the chunk step and the slice loop ------------------------------------------------------
 struct KeptLds {
   float4 *box;  // [Rc] (Rc a multiple of 4; null boxes from the kept count up to the next multiple of 4)
@@ -450,16 +470,7 @@ __device__ __forceinline__ int nms_chunk_resolve(const NmsLds<CH> &L, int nc, in
       if (left > 0 && cnt < R) {  // wave-uniform
         const unsigned long long valid = (left >= 64) ? ~0ull : ((1ull << left) - 1ull);
         const unsigned long long col = L.mask[(g * 64 + lane) * G + g];
-        unsigned long long und = ~deadw[g] & valid;
-        unsigned long long keptbits = 0ull;
-        while (und != 0ull) {
-          const bool in1 = (und >> lane) & 1ull;
-          und &= ~ballot64(in1 && (col & keptbits) != 0ull);
-          const bool in2 = (und >> lane) & 1ull;
-          const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
-          keptbits |= k;
-          und &= ~k;
-        }
+        unsigned long long keptbits = resolve_rounds(col, uniform64(~deadw[g] & valid));
         if (cnt + __popcll(keptbits) > R) {  // the greedy scan stops at R: keep the first R - cnt of them
           unsigned long long t = 0ull, bb = keptbits;
           for (int k = cnt; k < R; ++k) {
@@ -595,16 +606,7 @@ __device__ __forceinline__ int nms_slice64(const float4 *sbox, const float *sare
       asm volatile("" : "+v"(deadv), "+v"(col), "+v"(regv), "+v"(cb.x), "+v"(cb.y), "+v"(cb.z), "+v"(cb.w), "+v"(ca), "+v"(cf), "+v"(ci));
       const unsigned long long deadw = uniform64(deadv);
       const unsigned long long valid = (nc >= 64) ? ~0ull : ((1ull << nc) - 1ull);
-      unsigned long long und = ~deadw & valid;
-      unsigned long long keptbits = 0ull;
-      while (und != 0ull) {
-        const bool in1 = (und >> lane) & 1ull;
-        und &= ~ballot64(in1 && (col & keptbits) != 0ull);
-        const bool in2 = (und >> lane) & 1ull;
-        const unsigned long long k = ballot64(in2 && (col & und) == 0ull);
-        keptbits |= k;
-        und &= ~k;
-      }
+      unsigned long long keptbits = resolve_rounds(col, ~deadw & valid);
       int cnt = nk;
       if (cnt + __popcll(keptbits) > R) {  // the greedy scan stops at R: keep the first R - cnt of them
         unsigned long long t = 0ull, bb = keptbits;
