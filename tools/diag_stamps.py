@@ -33,6 +33,21 @@ if len(sys.argv) >= 2 and sys.argv[1] == "decoder":  # python tools/diag_stamps.
     for i in range(n):
         print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
     sys.exit(0)
+if len(sys.argv) >= 2 and sys.argv[1] == "targets":  # python tools/diag_stamps.py targets [B]  -> rpn_targets_kernel's stamps (cfg4)
+    B_ = int(sys.argv[2]) if len(sys.argv) >= 3 else 8
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    gt, lab = synth.gt_boxes(0, B_, 100)
+    gt, lab = torch.as_tensor(gt).cuda(), torch.as_tensor(lab).cuda()
+    buf = np.zeros(256, dtype=np.int64)
+    for it in range(3):
+        pkg.train_utils.calculate_rpn_actual_outputs(anchors, gt, lab, hp, seed=it)
+        torch.cuda.synchronize()
+        n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+    for i in range(n):
+        print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
+    sys.exit(0)
 # optional: G K R on the command line (default BASELINE config 2: 32 6000 300; config 5: 63 12000 300)
 G_, K_, R_ = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (32, 6000, 300)
 hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G_, pre_nms_topn=K_, test_nms_topn=R_)
