@@ -552,8 +552,14 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
   // without warm-up, 172-175 with.  Sweeping every image's RoIs top to bottom (FRCNN_CROP_SORT=1, roi_order_kernel) is
   // SLOWER (S = 8 279, S = 4 253-266, S = 2 246) although its HBM traffic is ideal (FETCH 160 MB for 146 MB of feature
   // maps, WRITE 537 MB).  FRCNN_CROP_SPLIT = S forces S (0 = never this schedule).
+  // A launch of at most 1024 boxes (batch 1-3 at 300 RoIs) does not fill the chip with one workgroup per box -- four fit on a
+  // CU -- and is bound by the time ONE workgroup takes for its 113 KB crop: the same split, four workgroups per box, no
+  // warm-up, runs the crop of config 1 in 12.6 instead of 16.6 us (B = 2: -10 %, B = 3: -12 %, B = 4: -3 %, B = 8: none).
   int S = knob(kKnobCropSplit, -1);
-  if (S < 0) S = image_bytes <= 4ll * 1024 * 1024 ? 0 : (image_bytes <= 5ll * 1024 * 1024 ? 2 : (image_bytes <= 10ll * 1024 * 1024 ? 4 : 8));
+  const bool small_launch = S < 0 && image_bytes <= 4ll * 1024 * 1024 && n <= 1024;
+  if (S < 0)
+    S = small_launch ? 4
+                     : (image_bytes <= 4ll * 1024 * 1024 ? 0 : (image_bytes <= 5ll * 1024 * 1024 ? 2 : (image_bytes <= 10ll * 1024 * 1024 ? 4 : 8)));
   const bool shape_ok = H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
                         aligned_to(out, 16) && aligned_to(rois, 16) && (long long)crop_h * crop_w * C * 4 < (1ll << 32) &&
                         image_bytes < (1ll << 32) && (long long)crop_h * crop_w < (1ll << 24);
@@ -573,7 +579,7 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
     // warm-up workgroups (unsorted sweep only: a sorted sweep has no "first box of the next image" in slot order that
     // the image-by-image warm-up could lead): FRCNN_CROP_PREFETCH as for the box kernel; by default 32 workgroups per (XCD,
     // image), one image (R boxes) ahead: 16 / 32 / 96 workgroups -> 194 / 190 / 190 us, lead 128 / 200 / 300 -> 221 / 199 / 193
-    int pf = order ? 0 : knob(kKnobCropPrefetch, 32), lead = R < 128 ? 128 : (R > 512 ? 512 : R), linear = 0;
+    int pf = order ? 0 : knob(kKnobCropPrefetch, small_launch ? 0 : 32), lead = R < 128 ? 128 : (R > 512 ? 512 : R), linear = 0;
     if (pf >= 100000000) {  // diagnostic: + 100000000 = linear (Infinity Cache) warm-up instead of the XCD's own slice
       linear = 1;
       pf -= 100000000;
