@@ -21,8 +21,10 @@ Multi-GPU: pure data parallel over images, one process per GPU, contiguous image
 collective on the data path; torch.distributed is used only for the barrier and the max-over-ranks time.  The small
 per-image outputs are gathered on the host inside the timed region: per rank into pinned memory (config 2: every rank is
 an independent replica), into one shared host buffer in shard order (configs 3-5: sharding.SharedHostGather).
-The K timed steps are repeated `--blocks` times (each block bracketed by barrier + synchronize, max over ranks);
-`value` is the median block, min / max are reported beside it.  Every step reads a different one of >= depth input sets,
+The K timed steps are repeated `--blocks` times.  Each block is bracketed by barrier + synchronize; a rank's clock stops
+when ITS work is complete (streams drained, its rows in the shared host buffer) and BEFORE the closing barrier, so no
+collective sits inside the timed bracket; the block's time is the maximum over the ranks of those local times (per-rank
+minimum beside it).  `value` is the median block, min / max are reported beside it.  Every step reads a different one of >= depth input sets,
 so no step finds its inputs in L2 / Infinity Cache.  Rank 0 prints ONE JSON line.
 """
 
@@ -109,9 +111,11 @@ def iou_map_bytes_per_image(cfg) -> int:
 
 
 def pmc_traffic_bytes(kernel_substr: str):
-    """HBM bytes per launch of one batch from the committed rocprofv3 --pmc passes (profiles/r*_pmc_*): separate FETCH_SIZE
-    and WRITE_SIZE runs, KB units, FETCH_SIZE doubled (gfx950 counts 128-B read requests as 64 B, MI355X_MICROARCH.md
-    section HBM).  The most recent round's pass wins.  None if the profiles are not there."""
+    """(HBM bytes per launch of one batch, the files they come from) from the committed rocprofv3 --pmc passes
+    (profiles/r*_pmc_*): separate FETCH_SIZE and WRITE_SIZE runs, KB units, FETCH_SIZE doubled (gfx950 counts 128-B read
+    requests as 64 B, MI355X_MICROARCH.md section HBM).  The most recent round's pass wins.  (None, None) if the profiles
+    are not there.  This is a figure measured in an earlier run of the same workload, not in this one: a --pmc pass
+    serialises the kernels and cannot ride along with the timed run."""
     import csv
     import glob
 
@@ -124,13 +128,13 @@ def pmc_traffic_bytes(kernel_substr: str):
                 for row in csv.DictReader(fh):
                     if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
                         vals.append(float(row["Counter_Value"]))
-        return sum(vals) / len(vals) if vals else None
+        return (sum(vals) / len(vals) if vals else None), (os.path.relpath(paths[-1], ROOT) if paths else None)
 
-    fetch = avg("r*_pmc_fetch_size_*.csv", "FETCH_SIZE")
-    write = avg("r*_pmc_write_size_*.csv", "WRITE_SIZE")
+    fetch, f_src = avg("r*_pmc_fetch_size_*.csv", "FETCH_SIZE")
+    write, w_src = avg("r*_pmc_write_size_*.csv", "WRITE_SIZE")
     if fetch is None or write is None:
-        return None
-    return int((2.0 * fetch + write) * 1024)
+        return None, None
+    return int((2.0 * fetch + write) * 1024), [f_src, w_src]
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -214,6 +218,28 @@ class Workload:
             self.bound = "hbm"
         self.seed = seed
 
+    def make_pipeline(self, depth, group, host_outputs=False, gather=None):
+        """The stage pipeline for this workload: inference (RoIBBox | RoIPooling | Decoder) or training (RoIBBox | RoIPooling,
+        RoIDelta beside the crop); None for target assignment."""
+        kind = self.cfg["kind"]
+        if kind == "targets" or self.B <= 0:
+            return None
+        depth = max(depth, group)
+        if kind == "infer":
+            return self.pkg.pipeline.RoIPathPipeline(self.roi_bbox, self.roi_pool, self.decoder, depth=depth, crop_group=group,
+                                                     host_outputs=host_outputs, gather=gather)
+        return self.pkg.pipeline.RoIPathPipeline(self.roi_bbox, self.roi_pool, depth=depth, crop_group=group, roi_delta=self.roi_delta,
+                                                 host_outputs=host_outputs, gather=gather)
+
+    def submit(self, pipe, i, ev=None):
+        """One step handed to the stage pipeline (every step is a full pass over its batch; the stages of consecutive steps
+        overlap).  `ev` brackets the crop kernel on ITS stream; the step index rides along as the gather's tag."""
+        s = self.sets[i % len(self.sets)]
+        if self.cfg["kind"] == "infer":
+            pipe.submit(s[0], s[1], s[2], (s[3], s[4]), timing=ev, tag=i)
+        else:
+            pipe.submit(s[0], s[1], s[2], None, timing=ev, gt=(s[3], s[4]), seed=self.seed + i, tag=i)
+
     def sections(self):
         """(name, per-image shape, dtype) of the small outputs that go to the host every step."""
         t, c = self.torch, self.cfg
@@ -251,6 +277,31 @@ class Workload:
             return {"roi_bboxes": rois, "bboxes": boxes, "labels": labels, "scores": scores}
         self.roi_delta([rois, s[3], s[4]], seed=self.seed + i)
         return {"roi_bboxes": rois}
+
+
+class IouMapCase:
+    """generate_iou_map (utils/bbox_utils.py:138-160), the map materialised: anchors (N,4) x gt (B,M,4) -> (B,N,M).  SURVEY.md
+    8d's algorithmic bytes: N*M*4 + M*16 per image, + N*16 (the shared anchors) once per launch."""
+
+    def __init__(self, pkg, cfg, B, seed, device, n_sets=4):
+        import torch
+
+        import synth
+        hp = pkg.train_utils.get_hyper_params(cfg["backbone"], feature_map_shape=cfg["G"])
+        self.pkg, self.B = pkg, B
+        self.anchors = pkg.bbox_utils.generate_anchors(hp)
+        N = self.anchors.shape[0]
+        self.sets = [torch.as_tensor(synth.gt_boxes(seed * 1000 + s, B, cfg["M"])[0]).to(device) for s in range(n_sets)]
+        self.bytes = iou_map_bytes_per_image(cfg) * B + N * 16
+        self.cur = torch.cuda.current_stream(device).cuda_stream
+
+    def step(self, i, ev=None):
+        if ev:
+            ev[0].record(self.cur)
+        out = self.pkg.bbox_utils.generate_iou_map(self.anchors, self.sets[i % len(self.sets)])
+        if ev:
+            ev[1].record(self.cur)
+        return out
 
 
 def stats(samples):
@@ -330,17 +381,18 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--spin-up-ms", type=float, default=300.0,
                     help="untimed steps of the same workload for this many milliseconds before the W warm-up steps (GPU clocks "
-                         "ramp up over tens of milliseconds of load; 0 = none)")
+                         "ramp up over tens of milliseconds of load; 0 = none).  One block timed BEFORE it is reported as cold_start")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each; value = the median block")
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="override the config's (global / per-GPU) batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("pipeline", "sequential"), default=None,
-                    help="pipeline (default for config 2): stages on three HIP streams, --depth batches in flight "
+                    help="pipeline (default for configs 2, 3, 5): stages on three HIP streams, --depth batches in flight "
                          "(tf_faster_rcnn_amd.pipeline); sequential: the layers one after the other on one stream")
-    ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--crop-group", type=int, default=2,
-                    help="pipeline mode: consecutive batches that share one launch per stage (the *_multi entry points)")
+    ap.add_argument("--depth", type=int, default=None, help="batches in flight in the stage pipeline (default 8; 4 for configs 3 / 5)")
+    ap.add_argument("--crop-group", type=int, default=None,
+                    help="pipeline mode: consecutive batches that share one launch per stage (the *_multi entry points); "
+                         "default 2 for config 2, 1 otherwise")
     ap.add_argument("--input-sets", type=int, default=0, help="distinct input sets rotated through the steps (0 = automatic)")
     ap.add_argument("--no-host-gather", action="store_true",
                     help="leave the small per-image outputs (RoIs, detections) on the GPU instead of copying them to host "
@@ -355,7 +407,7 @@ def main() -> int:
                     help="configs 3-5: rank 0 saves the gathered host arrays of the last step (npz, with the seed of its input "
                          "set) -- what tests/test_gpu_dist.py compares with the oracle")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="do not time config 1 and the per-GPU shards of configs 3-5 after the headline")
+                    help="do not time config 1, the per-GPU shards of configs 3-5 and the materialised IoU map after the headline")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -402,133 +454,166 @@ def main() -> int:
         shard = (lo, hi, b_global)
     else:
         b_local, b_global = cfg["B"], cfg["B"] * world
-    mode = args.mode or ("pipeline" if (args.config == 2 and cfg["kind"] == "infer") else "sequential")
-    if mode == "pipeline" and cfg["kind"] != "infer":
-        raise SystemExit("--mode pipeline is the RoIBBox -> RoIPooling -> Decoder stage pipeline (configs 1, 2, 5)")
+    mode = args.mode or ("pipeline" if (args.config in (2, 3, 5) and cfg["kind"] != "targets") else "sequential")
+    if mode == "pipeline" and cfg["kind"] == "targets":
+        raise SystemExit("--mode pipeline is the RoIBBox | RoIPooling | Decoder / RoIDelta stage pipeline (configs 1, 2, 3, 5)")
     gather = not args.no_host_gather
+    depth = args.depth or (8 if args.config == 2 else 4)
+    group = args.crop_group or (2 if args.config == 2 else 1)
 
-    def auto_sets(c, b):
+    def auto_sets(c, b, pipelined):
         if args.input_sets:
             return args.input_sets
         per_set = b * (c["G"] * c["G"] * c.get("C", 0) * 4 + c["G"] * c["G"] * 9 * 20)
         want = int(np.ceil(640e6 / max(per_set, 1)))  # > the 256 MiB Infinity Cache, with margin
-        return int(min(max(want, 3, (args.depth + 2) if mode == "pipeline" else 3), 16))
+        return int(min(max(want, 3, (depth + 2) if pipelined else 3), 16))
 
-    n_sets = auto_sets(cfg, max(b_local, 1))
+    n_sets = auto_sets(cfg, max(b_local, 1), mode == "pipeline")
     wl = Workload(pkg, cfg, b_local, seed=1 if strong else rank + 1, device=device, n_sets=n_sets, shard=shard)
     cur = torch.cuda.current_stream(device).cuda_stream
     timing_flags = pkg._lib.hipEventDisableSystemFence  # timing events without the system-scope fence: a default event makes
     # the kernel it follows write back and invalidate L2, which is exactly what the measurement must not add
 
-    def barrier(pipe=None):
+    def local_sync(pipe, sh):
+        """This rank's work is complete: streams drained and (sharded configs) its rows in the shared host buffer."""
         if pipe is not None:
             pipe.synchronize()
         torch.cuda.synchronize()
-        if shared is not None:
-            shared.flush()  # the last steps' rows reach the shared host buffer inside the timed region
+        if sh is not None:
+            sh.flush()
+
+    def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
 
-    shared = None
-
-    def max_over_ranks(x):
+    def over_ranks(x):
+        """(max, min) of a local figure over the ranks."""
         if dist is None:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            return x, x
+        t = torch.tensor([x, -x], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(t[0].item()), -float(t[1].item())
 
-    def run_blocks(step_fn, steps, warmup, blocks, every, pipe=None, spin_ms=0.0):
-        """`blocks` timed blocks of `steps` steps.  Returns (per-block seconds [max over ranks], event pairs, host enqueue s/step)."""
-        n_ev = blocks * ((steps + every - 1) // every) if every else 0
+    def run_blocks(step_fn, steps, warmup, blocks, every, pipe=None, sh=None, spin_ms=0.0, cold_block=False):
+        """`blocks` timed blocks of `steps` steps.  Returns a dict: per-block seconds (max over ranks) and their per-rank minima,
+        the event pairs' milliseconds, host enqueue seconds per step, the index of the last step, and -- with cold_block -- the
+        same figures of ONE block timed before the spin-up."""
+        n_ev = (blocks + (1 if cold_block else 0)) * ((steps + every - 1) // every) if every else 0
         evs = [(pkg._lib.HipEvent(timing_flags), pkg._lib.HipEvent(timing_flags)) for _ in range(n_ev)]
-        used = []
-        # Device spin-up (untimed, BEFORE the W warm-up steps, disclosed as "spin_up_ms" in the JSON line): the same steps for
-        # a fixed wall time.  A fresh process finds the GPU in its idle power state and the clocks keep rising for some tens
-        # of milliseconds of load: with --steps 20 --warmup 5 the timed blocks of one run read 0.154, 0.164, 0.153, 0.149,
-        # 0.145, ... 0.136 ms per step, i.e. the first blocks measure the power management, not the kernels.
-        t_spin = time.perf_counter()
-        n_spin = 0
-        while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
-            for _ in range(16):
-                step_fn(n_spin, None)
-                n_spin += 1
-            if pipe is not None:
-                pipe.synchronize()
-            torch.cuda.synchronize()
-        for i in range(warmup):
-            step_fn(i, None)
-        times, host = [], []
-        g = warmup
-        for _ in range(blocks):
-            barrier(pipe)
+        state = {"g": 0, "ev": 0}
+
+        def one_block():
+            local_sync(pipe, sh)
+            barrier()
+            used = []
             wait0 = pipe.wait_seconds if pipe is not None else 0.0
             t0 = time.perf_counter()
             for i in range(steps):
                 ev = None
                 if every and i % every == 0:
-                    ev = evs[len(used)]
+                    ev = evs[state["ev"]]
+                    state["ev"] += 1
                     used.append(ev)
-                step_fn(g, ev)
-                g += 1
-            host.append(time.perf_counter() - t0 - ((pipe.wait_seconds - wait0) if pipe is not None else 0.0))
-            barrier(pipe)
-            times.append(max_over_ranks(time.perf_counter() - t0))
-        samples = [a.elapsed_time(b) for a, b in used]
-        return times, samples, float(np.median(host)) / max(steps, 1)
+                step_fn(state["g"], ev)
+                state["g"] += 1
+            host = time.perf_counter() - t0 - ((pipe.wait_seconds - wait0) if pipe is not None else 0.0)
+            local_sync(pipe, sh)
+            local = time.perf_counter() - t0  # the clock stops BEFORE the closing barrier: no collective inside the bracket
+            barrier()
+            t_max, t_min = over_ranks(local)
+            return t_max, t_min, host, [a.elapsed_time(b) for a, b in used]
+
+        out = {}
+        for _ in range(warmup):
+            step_fn(state["g"], None)
+            state["g"] += 1
+        if cold_block:
+            # One block timed BEFORE the spin-up: what the driver's `--warmup W` alone would have measured on a GPU that was
+            # idle a moment ago (clocks still ramping).  Reported as cold_start, never part of `value`.
+            t_max, _, _, smp = one_block()
+            out["cold"] = (t_max, smp)
+        # Device spin-up (untimed, disclosed as "spin_up_ms" in the JSON line): the same steps for a fixed wall time.  A fresh
+        # process finds the GPU in its idle power state and the clocks keep rising for some tens of milliseconds of load: with
+        # --steps 20 --warmup 5 the timed blocks of one run read 0.154, 0.164, 0.153, 0.149, 0.145, ... 0.136 ms per step, i.e.
+        # the first blocks measure the power management, not the kernels.
+        t_spin = time.perf_counter()
+        n_spin = 0  # (its own counter: the number of spin-up steps differs from rank to rank, the step index must not)
+        while (time.perf_counter() - t_spin) * 1e3 < spin_ms:
+            for _ in range(16):
+                step_fn(n_spin, None)
+                n_spin += 1
+            local_sync(pipe, sh)
+        if spin_ms > 0:
+            for _ in range(warmup):  # the contract's W warm-up steps, directly in front of the timed blocks
+                step_fn(state["g"], None)
+                state["g"] += 1
+        times, mins, host, samples = [], [], [], []
+        for _ in range(blocks):
+            t_max, t_min, h, smp = one_block()
+            times.append(t_max)
+            mins.append(t_min)
+            host.append(h)
+            samples += smp
+        out.update(times=times, rank_min=mins, samples=samples, host_s=float(np.median(host)) / max(steps, 1), last_step=state["g"] - 1)
+        return out
 
     # ---- the host gather of the small outputs ------------------------------------------------------------------------
-    pinned = None
-    if gather and mode == "sequential":
-        if strong:
-            shared = sharding.SharedHostGather(wl.sections(), b_global, slots=4, rank=rank, world_size=world, device=device)
-        else:
-            pinned = {n: torch.empty((b_local,) + tuple(shape), dtype=dt, pin_memory=True) for n, shape, dt in wl.sections()}
+    def make_gather(w, b_glob, rk, wd, pipelined):
+        """(shared, pinned): strong-scaling configs gather into ONE shared host buffer in shard order
+        (sharding.SharedHostGather), config 2's replicas into per-rank pinned memory."""
+        if not gather:
+            return None, None
+        if w.cfg["scaling"] == "strong":
+            return sharding.SharedHostGather(w.sections(), b_glob, slots=max(4, depth + 1) if pipelined else 4, rank=rk,
+                                             world_size=wd, device=device), None
+        if pipelined:
+            return None, None  # the pipeline's own host_outputs
+        return None, {n: torch.empty((w.B,) + tuple(shape), dtype=dt, pin_memory=True) for n, shape, dt in w.sections()}
 
-    def step_sequential(i, ev, w=None, sh=None, pin=None):
-        w = w or wl
-        outs = w.step(i, ev)
-        sh = shared if sh is None else sh
-        pin = pinned if pin is None else pin
-        if sh:
-            sh.write_step(i, outs, cur)
-        elif pin:  # the host gather of the small outputs: one copy kernel for all of them
-            pkg._lib.gather_copy_multi([(outs[name].data_ptr(), dst.data_ptr(), outs[name].numel() * 4) for name, dst in pin.items()], cur)
-        return outs
+    def sequential_step(w, sh, pin):
+        def step(i, ev):
+            outs = w.step(i, ev)
+            if sh is not None:
+                sh.write_step(i, outs, cur)
+            elif pin:  # the host gather of the small outputs: one copy kernel for all of them
+                pkg._lib.gather_copy_multi([(outs[name].data_ptr(), dst.data_ptr(), outs[name].numel() * 4) for name, dst in pin.items()], cur)
+            return outs
+        return step
 
-    pipe = None
-    group = args.crop_group
-    if cfg["kind"] == "infer" and b_local > 0:
-        pipe = pkg.pipeline.RoIPathPipeline(wl.roi_bbox, wl.roi_pool, wl.decoder, depth=args.depth, crop_group=group,
-                                            host_outputs=gather)
+    def pipeline_for(w, sh, d, g):
+        hook = (lambda tag, outs, q: sh.write_step(tag, outs, q)) if sh is not None else None
+        return w.make_pipeline(d, g, host_outputs=gather and sh is None, gather=hook)
 
-    def step_pipeline(i, ev):
-        # every step is a full pass (RoIBBox -> RoIPooling -> Decoder) over its batch; the stages of up to --depth
-        # consecutive steps overlap on three streams.  The events bracket the crop kernel on ITS stream (with
-        # --crop-group g the first batch of a group carries the events of the group's one launch).
-        s = wl.sets[i % len(wl.sets)]
-        pipe.submit(s[0], s[1], s[2], (s[3], s[4]), timing=ev)
+    shared, pinned = make_gather(wl, b_global, rank, world, mode == "pipeline")
+    pipe = pipeline_for(wl, shared, depth, group) if (mode == "pipeline" or (world == 1 and not args.no_other_schedule)) and cfg["kind"] != "targets" else None
+    step_pipeline = (lambda i, ev: wl.submit(pipe, i, ev)) if pipe is not None else None
 
     if mode == "pipeline":
-        step, every = step_pipeline, TIME_EVERY * group
+        step, every, run_pipe = step_pipeline, TIME_EVERY * group, pipe
     else:
-        step, every = step_sequential, TIME_EVERY
-    times, samples, host_s = run_blocks(step, args.steps, args.warmup, args.blocks, every, pipe if mode == "pipeline" else None,
-                                        spin_ms=args.spin_up_ms)
+        step, every, run_pipe = sequential_step(wl, shared, pinned), TIME_EVERY, None
+    main_run = run_blocks(step, args.steps, args.warmup, args.blocks, every, run_pipe, shared, spin_ms=args.spin_up_ms,
+                          cold_block=args.spin_up_ms > 0)
+    times, samples, host_s = main_run["times"], main_run["samples"], main_run["host_s"]
+    gather_stats = shared.stats() if shared is not None else None
 
     launch_batches = group if mode == "pipeline" else 1  # batches one launch of the dominant kernel covers
     dom = stats(samples)
 
+    def frac_of(w, launch_ms, batches=1):
+        return w.dominant_bytes * batches / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
     other = None
-    if world == 1 and not args.no_other_schedule and cfg["kind"] == "infer":
+    if world == 1 and not args.no_other_schedule and cfg["kind"] != "targets":
         # the other schedule, same K steps, reported beside the headline (not part of `value`)
         if mode == "pipeline":
-            pinned = {n: torch.empty((b_local,) + tuple(shape), dtype=dt, pin_memory=True) for n, shape, dt in wl.sections()} if gather else None
-            o_times, _, _ = run_blocks(step_sequential, args.steps, min(args.warmup, 10), 3, 0)
+            o_sh, o_pin = make_gather(wl, b_global, rank, world, False)
+            o = run_blocks(sequential_step(wl, o_sh, o_pin), args.steps, min(args.warmup, 10), 3, 0, None, o_sh)
+            if o_sh is not None:
+                o_sh.close()
         else:
-            o_times, _, _ = run_blocks(step_pipeline, args.steps, min(args.warmup, 10), 3, 0, pipe)
-        o_med = float(np.median(o_times))
+            o = run_blocks(step_pipeline, args.steps, min(args.warmup, 10), 3, 0, pipe, shared)
+        o_med = float(np.median(o["times"]))
         other = {"mode": "sequential" if mode == "pipeline" else "pipeline", "value": round(b_global * args.steps / o_med, 1),
                  "ms_per_step": round(o_med / args.steps * 1e3, 4)}
 
@@ -546,44 +631,85 @@ def main() -> int:
                 wl.sets = all_sets[:1]
             else:
                 wl.sets = [(s[0] * 0.05,) + tuple(s[1:]) for s in all_sets]
-            t, smp, _ = run_blocks(step_pipeline, args.steps, min(args.warmup, 10), 3, every, pipe)
-            med = float(np.median(t))
-            d = stats(smp)
-            ach = wl.dominant_bytes * launch_batches / (d["mean"] * 1e-3) / 1e9
+            o = run_blocks(step_pipeline, args.steps, min(args.warmup, 10), 3, every, pipe)
+            med = float(np.median(o["times"]))
+            d = stats(o["samples"])
             other_inputs[name] = {"value": round(b_global * args.steps / med, 1), "ms_per_step": round(med / args.steps * 1e3, 4),
-                                  "crop_launch_ms": round(d["mean"], 5), "crop_frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4),
+                                  "crop_launch_ms": round(d["mean"], 5),
+                                  "crop_frac_of_hbm_peak": round(frac_of(wl, d["mean"], launch_batches), 4),
                                   "input_sets": len(wl.sets)}
         wl.sets = all_sets
 
+    def kernel_report(name, bound, d, nbytes):
+        ach = nbytes / (d["mean"] * 1e-3) / 1e9
+        return {"kernel": name, "bound": bound, "avg_launch_ms": round(d["mean"], 5),
+                "launch_ms_p10_p50_p90": [round(d[q], 5) for q in ("p10", "p50", "p90")], "launches_timed": d["n"],
+                "bytes_per_launch": nbytes, "achieved_GBps": round(ach, 1), "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4)}
+
     others = None
     if world == 1 and args.config == 2 and not args.no_other_configs:
+        # Config 1 and ONE GPU's shard of configs 3 / 4 / 5 as BASELINE.json deploys them, each through the host path of that
+        # deployment: the shard's small outputs go into a SharedHostGather (world 1 here: same calls, same host work per step).
         others = {}
+        k = min(args.steps, 30)
         for c_id in (1, 3, 4, 5):
             c = dict(CONFIGS[c_id])
             c["B"] = SHARDS.get(c_id, c["B"])
-            w = Workload(pkg, c, c["B"], seed=7 + c_id, device=device, n_sets=auto_sets(c, c["B"]))
-            pin = {n: torch.empty((c["B"],) + tuple(shape), dtype=dt, pin_memory=True) for n, shape, dt in w.sections()} if gather else None
-            st = lambda i, ev, w=w, pin=pin: step_sequential(i, ev, w=w, sh=False, pin=pin)  # noqa: E731
-            k = min(args.steps, 30)
-            t, smp, _ = run_blocks(st, k, 5, 3, 1)
-            med = float(np.median(t))
-            d = stats(smp)
-            ach = w.dominant_bytes / (d["mean"] * 1e-3) / 1e9
-            others[f"config{c_id}" + ("_shard" if c_id in SHARDS else "")] = {
-                "workload": c["title"] + (f" -- one GPU's shard: {c['B']} images" if c_id in SHARDS else ""),
-                "schedule": "sequential on one stream", "images_per_step": c["B"], "steps": k, "blocks": 3,
-                "value": round(c["B"] * k / med, 1), "unit": "images/s", "ms_per_step": round(med / k * 1e3, 4),
-                "dominant_kernel": {"kernel": w.dominant, "bound": w.bound, "avg_launch_ms": round(d["mean"], 5),
-                                    "launch_ms_p10_p50_p90": [round(d[q], 5) for q in ("p10", "p50", "p90")],
-                                    "launches_timed": d["n"], "bytes_per_launch": w.dominant_bytes,
-                                    "achieved_GBps": round(ach, 1), "frac_of_hbm_peak": round(ach / HBM_PEAK_GBS, 4)}}
-            if c["kind"] == "infer" and c["B"] > 1:  # the same shard through the stage pipeline (4 batches in flight)
-                p2 = pkg.pipeline.RoIPathPipeline(w.roi_bbox, w.roi_pool, w.decoder, depth=4, crop_group=1, host_outputs=gather)
-                sp = lambda i, ev, w=w, p2=p2: p2.submit(*w.sets[i % len(w.sets)][:3], tuple(w.sets[i % len(w.sets)][3:5]))  # noqa: E731
-                t2, _, _ = run_blocks(sp, k, 5, 3, 0, p2)
-                others[f"config{c_id}_shard"]["stage_pipeline_value"] = round(c["B"] * k / float(np.median(t2)), 1)
-                del p2, sp
+            piped = c["kind"] != "targets" and c_id != 1
+            w = Workload(pkg, c, c["B"], seed=7 + c_id, device=device, n_sets=auto_sets(c, c["B"], piped))
+            sh, pin = make_gather(w, c["B"], 0, 1, False)
+            o = run_blocks(sequential_step(w, sh, pin), k, 5, 3, 1, None, sh)
+            med = float(np.median(o["times"]))
+            d = stats(o["samples"])
+            key = f"config{c_id}" + ("_shard" if c_id in SHARDS else "")
+            entry = {"workload": c["title"] + (f" -- one GPU's shard: {c['B']} images" if c_id in SHARDS else ""),
+                     "schedule": "sequential on one stream", "images_per_step": c["B"], "steps": k, "blocks": 3,
+                     "value": round(c["B"] * k / med, 1), "unit": "images/s", "ms_per_step": round(med / k * 1e3, 4),
+                     "host_enqueue_ms_per_step": round(o["host_s"] * 1e3, 4),
+                     "host_gather": ("shared host buffer (sharding.SharedHostGather, native worker thread)" if sh is not None else
+                                     "pinned host memory" if pin else "none"),
+                     "dominant_kernel": kernel_report(w.dominant, w.bound, d, w.dominant_bytes)}
+            if sh is not None:
+                st = sh.stats()
+                entry["host_gather_publish_ms_per_step"] = round(st["publish_seconds"] / max(st["jobs"], 1) * 1e3, 4)
+                entry["host_gather_submit_wait_ms_per_step"] = round(st["submit_wait_seconds"] / max(st["jobs"], 1) * 1e3, 4)
+                sh.close()
+            if piped:
+                # the same shard through the stage pipeline (4 batches in flight): the deployed schedule of configs 3 and 5;
+                # its figures become the entry's headline, the sequential ones stay beside them
+                sh2, _ = make_gather(w, c["B"], 0, 1, True)
+                p2 = pipeline_for(w, sh2, 4, 1)
+                o2 = run_blocks(lambda i, ev, w=w, p2=p2: w.submit(p2, i, ev), k, 5, 3, 1, p2, sh2)
+                med2 = float(np.median(o2["times"]))
+                d2 = stats(o2["samples"])
+                entry["sequential"] = {kk: entry[kk] for kk in ("value", "ms_per_step", "host_enqueue_ms_per_step", "dominant_kernel")}
+                entry.update(schedule="stage pipeline on 3 HIP streams, 4 batches in flight" +
+                             (" (train mode: RoIDelta beside the crop)" if c["kind"] == "train" else ""),
+                             value=round(c["B"] * k / med2, 1), ms_per_step=round(med2 / k * 1e3, 4),
+                             host_enqueue_ms_per_step=round(o2["host_s"] * 1e3, 4),
+                             dominant_kernel=kernel_report(w.dominant, w.bound, d2, w.dominant_bytes))
+                if sh2 is not None:
+                    st = sh2.stats()
+                    entry["host_gather_publish_ms_per_step"] = round(st["publish_seconds"] / max(st["jobs"], 1) * 1e3, 4)
+                    entry["host_gather_submit_wait_ms_per_step"] = round(st["submit_wait_seconds"] / max(st["jobs"], 1) * 1e3, 4)
+                    sh2.close()
+                del p2
+            others[key] = entry
             del w, pin
+            torch.cuda.empty_cache()
+        # generate_iou_map with the map materialised (north_star's second HBM-roofline kernel): config 4's global batch on one
+        # GPU and one GPU's shard of it.  Off the sharded path -- target assignment never writes the map -- and timed for the
+        # kernel's roofline only: every launch bracketed with HIP events.
+        for label, b_map in (("iou_map_cfg4", CONFIGS[4]["B"]), ("iou_map_cfg4_shard", SHARDS[4])):
+            case = IouMapCase(pkg, CONFIGS[4], b_map, seed=11, device=device)
+            o = run_blocks(case.step, k, 5, 3, 1)
+            med = float(np.median(o["times"]))
+            others[label] = {"workload": f"generate_iou_map (utils/bbox_utils.py:138-160), map materialised: anchors (9216,4) x gt ({b_map},100,4) "
+                                         f"-> ({b_map},9216,100) fp32", "images_per_step": b_map, "steps": k, "blocks": 3,
+                             "value": round(b_map * k / med, 1), "unit": "images/s", "ms_per_step": round(med / k * 1e3, 4),
+                             "dominant_kernel": kernel_report("iou_map_rows_kernel", "hbm (write) / valu (one correctly rounded divide per pair)",
+                                                              stats(o["samples"]), case.bytes)}
+            del case
             torch.cuda.empty_cache()
 
     devices = [dev_index]
@@ -597,9 +723,9 @@ def main() -> int:
         value = b_global * args.steps / med
         dom_bytes = wl.dominant_bytes * launch_batches
         achieved = dom_bytes / (dom["mean"] * 1e-3) / 1e9 if dom else float("nan")
-        traffic = None
+        traffic = traffic_source = None
         if cfg["kind"] != "targets" and args.config == 2:
-            t = pmc_traffic_bytes("crop_resize_kernel")
+            t, traffic_source = pmc_traffic_bytes("crop_resize_kernel")
             traffic = None if t is None else t * launch_batches
         result = {
             "metric": METRIC,
@@ -613,7 +739,10 @@ def main() -> int:
             "blocks": {"n": args.blocks, "value_median": round(value, 1),
                        "value_min": round(b_global * args.steps / max(times), 1),
                        "value_max": round(b_global * args.steps / min(times), 1),
-                       "ms_per_step_each": [round(t / args.steps * 1e3, 4) for t in times]},
+                       "ms_per_step_each": [round(t / args.steps * 1e3, 4) for t in times],
+                       "ms_per_step_each_fastest_rank": [round(t / args.steps * 1e3, 4) for t in main_run["rank_min"]],
+                       "clock": "per rank: stops when its streams are drained and its rows are in the host buffer, before the "
+                                "closing barrier; block time = max over ranks"},
             "host_enqueue_ms_per_step": round(host_s * 1e3, 4),
             "higher_is_better": True,
             "scaling": cfg["scaling"],
@@ -626,22 +755,39 @@ def main() -> int:
                        "parallelism": f"dp{world} over images, contiguous shards, no collectives",
                        "ranks": world, "devices": devices, "world_size_observed": dist.get_world_size() if dist else 1,
                        "dist_backend": (backend if dist else None), "dist_backend_note": backend_note,
-                       "schedule": (f"stage pipeline on 3 HIP streams, {args.depth} batches in flight, "
-                                    f"{group} consecutive batch(es) per launch of each stage" if mode == "pipeline"
-                                    else "sequential on one stream"),
+                       "schedule": (f"stage pipeline on 3 HIP streams, {depth} batches in flight, "
+                                    f"{group} consecutive batch(es) per launch of each stage" +
+                                    (" (train mode: RoIDelta beside the crop)" if cfg["kind"] == "train" else "")
+                                    if mode == "pipeline" else "sequential on one stream"),
                        "host_gather": ("none" if not gather else
                                        "every step, inside the timed region: " +
-                                       ("each rank's GPU copies its images' small outputs to pinned staging (copy kernel), the host "
-                                        "moves them into ONE shared host buffer in shard order (sharding.SharedHostGather)" if shared else
+                                       ("each rank's GPU copies its images' small outputs to pinned staging (copy kernel), the native "
+                                        "worker thread moves them into ONE shared host buffer in shard order (sharding.SharedHostGather)"
+                                        if shared is not None else
                                         "RoIs and detections of every batch copied to pinned host memory (copy kernel)") +
                                        "; pooled features stay on the GPU")},
             "roofline": {"kernel": wl.dominant, "bound": "hbm", "bound_note": wl.bound,
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": (None if traffic is None else
+                                            {"files": traffic_source, "note": "rocprofv3 --pmc passes of an earlier run of this workload "
+                                             "(WRITE_SIZE + 2 x FETCH_SIZE, KB), not collected in this run"}),
                          "bytes_per_launch": dom_bytes, "avg_launch_ms": round(dom["mean"], 5) if dom else None,
                          "launch_ms_p10_p50_p90": [round(dom[q], 5) for q in ("p10", "p50", "p90")] if dom else None,
                          "launches_timed": dom["n"] if dom else 0},
         }
+        if "cold" in main_run:
+            c_t, c_smp = main_run["cold"]
+            c_d = stats(c_smp)
+            result["cold_start"] = {"note": f"one block of {args.steps} steps timed after {args.warmup} warm-up steps and BEFORE the spin-up "
+                                            "(GPU clocks still ramping): what --warmup alone measures in a fresh process",
+                                    "value": round(b_global * args.steps / c_t, 1), "ms_per_step": round(c_t / args.steps * 1e3, 4),
+                                    "crop_frac": (round(dom_bytes / (c_d["mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                                  if c_d and cfg["kind"] != "targets" else None),
+                                    "dominant_launch_ms": round(c_d["mean"], 5) if c_d else None}
+        if gather_stats is not None and gather_stats["jobs"]:
+            result["host_gather_publish_ms_per_step"] = round(gather_stats["publish_seconds"] / gather_stats["jobs"] * 1e3, 4)
+            result["host_gather_submit_wait_ms_per_step"] = round(gather_stats["submit_wait_seconds"] / gather_stats["jobs"] * 1e3, 4)
         if other is not None:
             result["other_schedule"] = other
         if other_inputs:
@@ -651,13 +797,17 @@ def main() -> int:
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
             result["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(result), flush=True)
-    if args.dump_gather and shared is not None and rank == 0:
-        last = args.warmup + args.blocks * args.steps - 1
-        np.savez(args.dump_gather, set_seed=np.int64(-1 if wl.set_seeds[last % len(wl.sets)] is None else wl.set_seeds[last % len(wl.sets)]),
-                 global_batch=np.int64(b_global), world=np.int64(world),
-                 **{name: shared.view(last, name).numpy().copy() for name, _, _ in wl.sections()})
+    if args.dump_gather and shared is not None:
+        local_sync(pipe, shared)
+        barrier()
+        if rank == 0:
+            last = main_run["last_step"]
+            np.savez(args.dump_gather, set_seed=np.int64(-1 if wl.set_seeds[last % len(wl.sets)] is None else wl.set_seeds[last % len(wl.sets)]),
+                     global_batch=np.int64(b_global), world=np.int64(world),
+                     **{name: shared.view(last, name).numpy().copy() for name, _, _ in wl.sections()})
     if dist is not None:
         dist.barrier()
+    del pipe
     if shared is not None:
         shared.close()
     if dist is not None:

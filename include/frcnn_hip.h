@@ -180,6 +180,12 @@ int frcnn_decoder_multi(const float *const *rois, const float *const *deltas,
  * random_mask (B,N) int32; select: device int32, n_select == 1 or B entries.  out (B,N) uint8. */
 int frcnn_select_mask(const uint8_t *mask, const int32_t *random_mask, const int32_t *select,
                       int n_select, int B, int N, uint8_t *out, frcnn_stream_t stream);
+/* The same call (utils/train_utils.py:72-88) with the random integers drawn in-kernel: U[1, 10 * max(select)) as :82-83,
+ * from a counter-based hash of (seed, image, element); the maximum over `select` is taken on the device, so nothing is
+ * read back to the host.  Where tf.random.uniform raises (10 * max(select) <= 1) every `select` is <= 0 and the output is
+ * all zero. */
+int frcnn_select_mask_seeded(const uint8_t *mask, const int32_t *select, int n_select, uint64_t seed, int B,
+                             int N, uint8_t *out, frcnn_stream_t stream);
 
 /* utils/train_utils.py:149-202 calculate_rpn_actual_outputs.  anchors (N,4); gt_boxes (B,M,4);
  * gt_labels (B,M) int32 (-1 = padding).  rnd_pos / rnd_neg: (B,N) int32 random integers of the
@@ -229,6 +235,30 @@ int frcnn_gather_copy(const void *src, void *dst, size_t bytes, frcnn_stream_t s
  * 16-byte aligned and a multiple of 16 bytes.  (RoIs, boxes, labels and scores of a batch are four tensors.) */
 int frcnn_gather_copy_multi(const void *const *srcs, void *const *dsts, const size_t *bytes, int n,
                             frcnn_stream_t stream);
+
+/* ---- host gather runtime ----------------------------------------------------------------- */
+/* The final host gather of a batch sharded over the GPUs of one node, one object per rank (no counterpart in the
+ * reference: it is single-device; Keras' predict() returns host arrays, faster_rcnn_predictor.py:56).  A step's small
+ * outputs travel in two hops: frcnn_host_gather_submit launches ONE copy kernel on `stream` (srcs[i] -> stage[i], device
+ * memory -> this rank's pinned staging, the frcnn_gather_copy_multi rules: at most 8 segments, 16-byte aligned, multiples
+ * of 16 bytes), records the slot's event behind it and returns; a worker thread owned by the object waits for that event
+ * and copies stage[i] -> dsts[i] (host memory, normally this rank's rows of a POSIX-shared buffer that every rank maps).
+ * `slot` (0..slots-1) names the staging area the step uses: a submit blocks only while the job that last used the same
+ * slot has not been published (back-pressure; a running loop that walks the slots round robin never waits).
+ * frcnn_host_gather_flush blocks until every submitted job is in its destination.  These are the only entry points of
+ * the library that own host resources (events, a thread) or may block; all of them are host-side, none is a stream
+ * operation.  The device current at frcnn_host_gather_create owns the object; submit from one thread at a time. */
+typedef struct frcnn_host_gather frcnn_host_gather_t;
+int frcnn_host_gather_create(int slots, frcnn_host_gather_t **out);
+int frcnn_host_gather_submit(frcnn_host_gather_t *h, int slot, const void *const *srcs, void *const *stage,
+                             void *const *dsts, const size_t *bytes, int n, frcnn_stream_t stream);
+int frcnn_host_gather_flush(frcnn_host_gather_t *h);
+/* Diagnostics: seconds the worker spent copying, seconds submit spent blocked on back-pressure, jobs published.  Any
+ * pointer may be NULL. */
+int frcnn_host_gather_stats(frcnn_host_gather_t *h, double *publish_seconds, double *submit_wait_seconds,
+                            long long *jobs);
+/* Publishes what is queued, stops the worker, releases the events.  NULL is a no-op. */
+int frcnn_host_gather_destroy(frcnn_host_gather_t *h);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,7 @@ def test_fuzz_roi_bbox_all_schedules(pkg, knobs):
         knobs.setenv("FRCNN_PROPOSAL_EXACT_SLICES", "1" if (case // 6) % 2 else "0")   # exact-rank slices / sampled cuts
         knobs.setenv("FRCNN_PROPOSAL_CHUNK", ("64", "128", "256")[(case // 12) % 3])    # NMS chunk width
         knobs.setenv("FRCNN_SORT_RADIX_ONLY", "1" if (case // 9) % 2 else "0")         # full-sort kernel: bucket / radix
+        knobs.setenv("FRCNN_BITMASK_THREADS", "1024" if (case // 3) % 2 else "256")     # workgroup size of the bitmask scans
         hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
         hp.update(feature_map_shape=G, pre_nms_topn=K, test_nms_topn=R, nms_iou_threshold=thr)
         anchors = oracle.generate_anchors(hp)

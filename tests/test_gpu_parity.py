@@ -454,13 +454,15 @@ def test_roi_bbox_bitmask_path(pkg, knobs):
     """The whole-chip bitmask schedule (taken for post_nms_topn >= 512), forced on every shape: one and several phases,
     early finish, exhausted candidates, ties, K not a multiple of 64, R larger than K."""
     knobs.setenv("FRCNN_ROI_BBOX_BITMASK_MIN_R", "1")
-    for args, kw in (((10, 2, 8, 64, 16), {}), ((11, 2, 16, 2304, 300), {}), ((12, 4, 32, 6000, 300), {}),
-                     ((13, 3, 31, 6000, 2000), dict(mode="training")), ((14, 2, 16, 1000, 100), dict(unique=False, thr=0.5)),
-                     ((15, 2, 63, 12000, 1500), dict(mode="training")), ((16, 2, 8, 570, 600), {}),
-                     ((17, 2, 16, 2304, 1500), dict(thr=0.1))):
-        got, want = _roi_bbox_case(pkg, *args, **kw)
-        assert_bits(got, want, f"RoIBBox bitmask {args} {kw}")
-    test_roi_bbox_dense_suppression(pkg)
+    for threads in (256, 1024):  # the scans' workgroup size: 4 or 16 waves per image, same results
+        knobs.setenv("FRCNN_BITMASK_THREADS", threads)
+        for args, kw in (((10, 2, 8, 64, 16), {}), ((11, 2, 16, 2304, 300), {}), ((12, 4, 32, 6000, 300), {}),
+                         ((13, 3, 31, 6000, 2000), dict(mode="training")), ((14, 2, 16, 1000, 100), dict(unique=False, thr=0.5)),
+                         ((15, 2, 63, 12000, 1500), dict(mode="training")), ((16, 2, 8, 570, 600), {}),
+                         ((17, 2, 16, 2304, 1500), dict(thr=0.1))):
+            got, want = _roi_bbox_case(pkg, *args, **kw)
+            assert_bits(got, want, f"RoIBBox bitmask ({threads} threads) {args} {kw}")
+        test_roi_bbox_dense_suppression(pkg)
 
 
 def test_roi_bbox_dense_suppression(pkg):
@@ -677,6 +679,16 @@ def test_select_mask(pkg):
     # without injected integers: at most `select` kept, all inside the mask
     got = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(np.asarray([128], np.int32))).cpu().numpy()
     assert (got <= mask).all() and (got.sum(1) == np.minimum(mask.sum(1), 128)).all()
+    # the in-kernel draw (frcnn_select_mask_seeded: max(select) taken on the device, no host sync): per-image quotas,
+    # deterministic in the seed, a different sample for another seed, and nothing selected where tf.random.uniform raises
+    sel = np.asarray([0, 50, 4000, 7, 128], np.int32)
+    a = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(sel), seed=5).cpu().numpy()
+    b = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(sel), seed=5).cpu().numpy()
+    c = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(sel), seed=6).cpu().numpy()
+    assert (a <= mask).all() and (a.sum(1) == np.minimum(mask.sum(1), sel)).all()
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    none = pkg.train_utils.randomly_select_xyz_mask(dev(mask), dev(np.asarray([0], np.int32)), seed=1).cpu().numpy()
+    assert not none.any()
 
 
 @pytest.mark.parametrize("B,G,M", [(2, 8, 4), (8, 32, 100), (3, 31, 17)])
@@ -1050,6 +1062,62 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
 
 
+@pytest.mark.parametrize("depth,crop_group,R,with_heads", [(1, 1, 96, False), (3, 1, 600, True), (4, 2, 96, True), (3, 3, 600, False)])
+def test_train_pipeline_matches_oracle_and_sequential(pkg, depth, crop_group, R, with_heads):
+    """Train mode of the stage pipeline (models/faster_rcnn.py:327-335: RoIBBox -> RoIPooling, RoIDelta beside the crop):
+    per batch exactly the sequential layers' and the oracle's results, with the sampling integers injected -- on the fused
+    proposal kernel (R = 96) and on the whole-chip bitmask schedule (R = 600 >= 512), with and without grouped launches."""
+    from tf_faster_rcnn_amd import pipeline
+
+    B, G, C, L, M = 3, 16, 32, 6, 9
+    hp = pkg.train_utils.get_hyper_params("vgg16")
+    hp.update(feature_map_shape=G, pre_nms_topn=1500, train_nms_topn=R, total_labels=L, total_pos_bboxes=16, total_neg_bboxes=24)
+    anchors = oracle.generate_anchors(hp)
+    roi_bbox = pkg.faster_rcnn.RoIBBox(dev(anchors), "training", hp)
+    roi_pool = pkg.faster_rcnn.RoIPooling(hp)
+    roi_delta = pkg.faster_rcnn.RoIDelta(hp)
+    seen = []
+    pipe = pipeline.RoIPathPipeline(roi_bbox, roi_pool, depth=depth, crop_group=crop_group, roi_delta=roi_delta, host_outputs=True,
+                                    gather=lambda t, outs, q: seen.append((t, sorted(outs))))
+    with pytest.raises(ValueError):
+        pipeline.RoIPathPipeline(roi_bbox, roi_pool)  # neither decoder nor roi_delta
+    rng = np.random.default_rng(5)
+    batches, masks = [], []
+    for seed in range(5):
+        deltas, scores = synth.rpn_outputs(seed, B, G)
+        fm = synth.feature_map(seed, B, G, C)
+        gt, lab = synth.gt_boxes(seed, B, M, L)
+        batches.append((deltas, scores, fm, gt, lab))
+        masks.append((rng.integers(1, 160, (B, R)).astype(np.int32), rng.integers(1, 240, (B, R)).astype(np.int32)))
+    dev_batches = [tuple(dev(a) for a in b) for b in batches]
+    dev_masks = [tuple(dev(a) for a in m) for m in masks]
+    calls = []
+    heads = (lambda pooled, rois: calls.append(tuple(pooled.shape))) if with_heads else None
+    with pytest.raises(ValueError):
+        pipe.submit(*dev_batches[0][:3])  # train mode needs gt
+    got = {}
+    for i, b in enumerate(dev_batches):
+        assert pipe.submit(b[0], b[1], b[2], heads, gt=(b[3], b[4]), random_masks=dev_masks[i]) == i
+        if i >= depth - 1:
+            j = i - (depth - 1)
+            res = pipe.result(j)
+            got[j] = {k: v.clone() for k, v in res.items() if k != "host"}
+            assert_bits(res["host"]["roi_bboxes"], res["roi_bboxes"].cpu().numpy(), f"train pipeline batch {j} host copy of the RoIs")
+    for j in range(len(batches) - (depth - 1), len(batches)):
+        got[j] = {k: v.clone() for k, v in pipe.result(j, wait="stream").items() if k != "host"}
+    pipe.synchronize()
+    assert [t for t, _ in seen] == list(range(len(batches))) and all(names == ["roi_bboxes"] for _, names in seen)
+    assert len(calls) == (len(batches) if with_heads else 0)
+    for i, b in enumerate(batches):
+        rois = oracle.roi_bbox(b[0], b[1], anchors, hp["variances"], 1500, R, hp["nms_iou_threshold"])
+        pooled = oracle.roi_pooling(b[2], rois, hp["pooling_size"])
+        rd, rl = oracle.roi_delta(rois, b[3], b[4], hp, masks[i])
+        seq = pipeline.run_sequential_train(roi_bbox, roi_pool, roi_delta, dev_batches[i], random_masks=dev_masks[i])
+        for name, want in (("roi_bboxes", rois), ("roi_pooled", pooled), ("roi_bbox_deltas", rd), ("roi_bbox_labels", rl)):
+            assert_bits(got[i][name], want, f"train pipeline batch {i} {name} vs oracle")
+            assert_bits(got[i][name], seq[name].cpu().numpy(), f"train pipeline batch {i} {name} vs sequential")
+
+
 @pytest.mark.parametrize("nbytes", [16, 4096 + 7, 154_000, 3])
 def test_gather_copy_into_pinned_host_memory(pkg, nbytes):
     """frcnn_gather_copy: a kernel that copies device memory into device-mapped pinned host memory (and device to device),
@@ -1236,6 +1304,32 @@ def test_crop_and_resize_multi_matches_oracle(pkg, groups, C, H):
         _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_rois]),
                                                          arr(*[t.data_ptr() for t in outs]), 5, B, H, W, C, B * R, R, 7, 7,
                                                          0.0, stream))
+
+
+@pytest.mark.parametrize("groups,n,bpi,pf", [(4, 10, 4, 3), (3, 10, 4, 40005), (2, 37, 5, 7), (4, 97, 16, 10002)])
+def test_crop_and_resize_multi_ragged_triples_with_warmup(pkg, knobs, groups, n, bpi, pf):
+    """Grouped launch whose triples do not end on an image boundary (n % boxes_per_image != 0), warm-up workgroups forced
+    (FRCNN_CROP_PREFETCH = lead * 10000 + workgroups per image): an XCD's box range then spans more (partial) images than
+    whole ones, and every box must still get its slot.  Bit-exact against the oracle's crop_and_resize."""
+    import ctypes
+
+    from tf_faster_rcnn_amd import _lib
+
+    rng = np.random.default_rng(7 * groups + n)
+    B, H, W, C = (n + bpi - 1) // bpi, 6, 9, 8
+    fms = [rng.normal(0, 1, (B, H, W, C)).astype(np.float32) for _ in range(groups)]
+    boxes = [rng.uniform(-0.1, 1.1, (n, 4)).astype(np.float32) for _ in range(groups)]
+    ind = (np.arange(n) // bpi).astype(np.int32)
+    d_fm, d_boxes = [dev(a) for a in fms], [dev(a) for a in boxes]
+    outs = [torch.full((n, 7, 7, C), float("nan"), dtype=torch.float32, device="cuda") for _ in range(groups)]
+    arr = ctypes.c_void_p * groups
+    knobs.setenv("FRCNN_CROP_PREFETCH", pf)
+    _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_boxes]),
+                                                     arr(*[t.data_ptr() for t in outs]), groups, B, H, W, C, n, bpi, 7, 7, 0.0,
+                                                     torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for g in range(groups):
+        assert_bits(outs[g], oracle.crop_and_resize(fms[g], boxes[g], ind, (7, 7)), f"ragged crop multi triple {g} of {groups}")
 
 
 # ------------------------------------------------------------------------------------------------

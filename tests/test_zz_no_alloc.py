@@ -49,6 +49,7 @@ def _case(pkg, seed, B, G, M):
 
 
 def test_rpn_targets_static_matches_workspace_entry_point():
+    import oracle
     import tf_faster_rcnn_amd as pkg
 
     # first the larger input (config 4's per-GPU shard), then a smaller one on the same, now dirty, scratch
@@ -60,6 +61,13 @@ def test_rpn_targets_static_matches_workspace_entry_point():
             assert np.array_equal(got_l.view(np.uint32), want_l.view(np.uint32)), f"labels differ (B={B}, G={G}, M={M})"
             assert np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32)), f"deltas differ (B={B}, G={G}, M={M})"
             assert not np.isnan(got_l).any() and set(np.unique(got_l)) <= {-1.0, 0.0, 1.0}
+            if ints[0] is not None:
+                # with the sampling integers injected the entry point is a parity case of its own: the CPU oracle
+                # (utils/train_utils.py:149-202 restated), bit for bit
+                ora_d, ora_l = oracle.calculate_rpn_actual_outputs(anchors.cpu().numpy(), gt.cpu().numpy(), labels.cpu().numpy(), hp,
+                                                                   (rp.cpu().numpy(), rn.cpu().numpy()))
+                assert np.array_equal(got_l.reshape(ora_l.shape).view(np.uint32), ora_l.view(np.uint32)), "labels differ from the oracle"
+                assert np.array_equal(got_d.view(np.uint32), np.ascontiguousarray(ora_d).view(np.uint32)), "deltas differ from the oracle"
 
 
 def test_rpn_targets_static_rejects_sizes_beyond_the_scratch():

@@ -56,7 +56,14 @@ SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
     "frcnn_decoder_multi": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "frcnn_gather_copy": (_i, [_vp, _vp, _sz, _vp]),
     "frcnn_gather_copy_multi": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "frcnn_host_gather_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "frcnn_host_gather_submit": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "frcnn_host_gather_flush": (_i, [_vp]),
+    "frcnn_host_gather_stats": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                     ctypes.POINTER(ctypes.c_longlong)]),
+    "frcnn_host_gather_destroy": (_i, [_vp]),
     "frcnn_select_mask": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "frcnn_select_mask_seeded": (_i, [_vp, _vp, _i, ctypes.c_uint64, _i, _i, _vp, _vp]),
     "frcnn_rpn_targets_workspace_bytes": (_sz, [_i, _i, _i]),
     "frcnn_rpn_targets": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _i, _i, _i, _i, _i, _c_float_p, _vp, _vp,
                                _vp, _sz, _vp]),

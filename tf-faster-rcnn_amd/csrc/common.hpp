@@ -46,6 +46,7 @@ enum Knob {
   kKnobIouReduceSplit,   // FRCNN_IOU_REDUCE_SPLIT      0|1: the 64 boxes x 4 gt quarters form of the fused IoU reductions
   kKnobProposalExactSlices,  // FRCNN_PROPOSAL_EXACT_SLICES 1: the fused RoIBBox kernel cuts its slices by exact rank only
   kKnobSortRadixOnly,    // FRCNN_SORT_RADIX_ONLY       1: sort_select_kernel orders its slots by the stable radix sort only
+  kKnobBitmaskThreads,   // FRCNN_BITMASK_THREADS       256|1024: workgroup size of the whole-chip bitmask schedule's scan kernels
   kKnobCount
 };
 bool knob_set(Knob k);

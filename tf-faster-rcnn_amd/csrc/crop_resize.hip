@@ -465,7 +465,10 @@ static unsigned crop_warmup_grid(CropGroups &gr, int units, int boxes_per_image,
   gr.pf_blocks = pf;
   gr.pf_lead = lead;
   const int qmax = (units + 7) / 8;
-  const long long images_max = (qmax + boxes_per_image - 2) / boxes_per_image + 1;  // images an XCD's range can touch
+  long long images_max = (qmax + boxes_per_image - 2) / boxes_per_image + 1;  // images an XCD's range can touch
+  // grouped launch whose triples do not end on an image boundary: crop_slot_role restarts its image walk at every triple,
+  // so a range that spans g triple boundaries can hold g more (partial) images than the bound above
+  if (gr.n_per_group > 0 && gr.n_per_group % boxes_per_image != 0) images_max += kCropGroups - 1;
   const long long slots = qmax + images_max * pf;
   if (slots * 8 >= (1ll << 31)) return 0;
   return (unsigned)(slots * 8);

@@ -184,10 +184,16 @@ __global__ __launch_bounds__(256) void bm_tiles_kernel(BitmaskParams p, int cb0,
   bm_tile(p, b, cb, g, cb0, gx, lane, s_box[w], s_af[w]);
 }
 
-// One workgroup (1024 threads) per image.  LDS: removed[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
+// One workgroup of NW waves per image (NW = 16, or 4: a 256-thread workgroup of at most 128 VGPRs becomes resident beside
+// the workgroups of a running crop launch, a 1024-thread one only in that launch's tail -- the stage pipeline's train mode
+// runs this kernel under the previous batch's crop).  LDS: removed[nb] | kidx[R_nms] | diag[kBandBlocks * 64].
+template <int NW>
 __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int cb0, int last_phase,
                                               unsigned long long *s_words, unsigned long long *s_kept, int *s_nk) {
   if (p.state[b * 4 + 1]) return;
+  constexpr int NT = NW * 64;
+  constexpr int NF = kBandBlocks / NW;  // later blocks of the band one wave folds into per step
+  static_assert(NW * NF == kBandBlocks && kBandBlocks <= 32, "the waves' folds cover every later block of the band");
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int nb = p.nb, R = p.R_nms;
   int cb1 = cb0 + kBandBlocks;
@@ -197,15 +203,15 @@ __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int
   int *kidx = reinterpret_cast<int *>(s_words + nb);
   const unsigned long long *mask = p.mask + (long long)b * nb * BW;
   int nk = p.state[b * 4 + 0];
-  for (int i = tid; i < nb; i += 1024) removed[i] = p.removed[(long long)b * nb + i];
-  for (int i = tid; i < nk; i += 1024) kidx[i] = p.kidx[(long long)b * R + i];
+  for (int i = tid; i < nb; i += NT) removed[i] = p.removed[(long long)b * nb + i];
+  for (int i = tid; i < nk; i += NT) kidx[i] = p.kidx[(long long)b * R + i];
   __syncthreads();
 
   // (i) the boxes kept in earlier bands suppress into this band: one wave per column block; a column is removed if any of
   // its words over the kept rows is non-zero (row slots past nk hold boxes that overlap nobody)
   if (cb0 > 0 && nk > 0) {
     const unsigned long long *xm = p.xmask + (long long)b * nb * p.Rx;
-    for (int cb = cb0 + w; cb < cb1; cb += 16) {
+    for (int cb = cb0 + w; cb < cb1; cb += NW) {
       unsigned long long acc = 0ull;
       const unsigned long long *col = xm + (long long)cb * p.Rx;
 #pragma unroll 4
@@ -220,20 +226,25 @@ __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int
   // one block ahead of the serial chain: the band's diagonal tiles sit in LDS, the words to fold after block
   // cb + 1 are requested while block cb is resolved.
   unsigned long long *s_diag = reinterpret_cast<unsigned long long *>(kidx + ((R + 1) & ~1));  // [kBandBlocks * 64]
-  for (int i = tid; i < (cb1 - cb0) * 64; i += 1024) {  // diagonal tile of block cb0 + i/64: row group i/64 of its own column
+  for (int i = tid; i < (cb1 - cb0) * 64; i += NT) {  // diagonal tile of block cb0 + i/64: row group i/64 of its own column
     const int blk = i >> 6;
     s_diag[i] = mask[(long long)(cb0 + blk) * BW + blk * 64 + (i & 63)];
   }
-  unsigned long long f1n = 0ull, f2n = 0ull;
-  if (cb0 + 1 + w < cb1) f1n = mask[(long long)(cb0 + 1 + w) * BW + lane];
-  if (cb0 + 17 + w < cb1) f2n = mask[(long long)(cb0 + 17 + w) * BW + lane];
+  unsigned long long fn[NF];  // wave w folds into blocks cb + 1 + w + j * NW, j < NF
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int c = cb0 + 1 + w + j * NW;
+    fn[j] = (c < cb1) ? mask[(long long)c * BW + lane] : 0ull;
+  }
   __syncthreads();
   for (int cb = cb0; cb < cb1 && nk < R; ++cb) {
-    const int c1 = cb + 1 + w, c2 = c1 + 16;
-    const unsigned long long f1 = f1n, f2 = f2n;
-    f1n = f2n = 0ull;
-    if (c1 + 1 < cb1) f1n = mask[(long long)(c1 + 1) * BW + (cb + 1 - cb0) * 64 + lane];
-    if (c2 + 1 < cb1) f2n = mask[(long long)(c2 + 1) * BW + (cb + 1 - cb0) * 64 + lane];
+    unsigned long long f[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int c = cb + 1 + w + j * NW;
+      f[j] = fn[j];
+      fn[j] = (c + 1 < cb1) ? mask[(long long)(c + 1) * BW + (cb + 1 - cb0) * 64 + lane] : 0ull;
+    }
     if (w == 0) {
       // Greedy order inside the block, in parallel rounds instead of one serial step per suppressing row: lane i knows
       // which earlier rows of the block suppress it (col).  A candidate hit by a KEPT row is removed; a candidate none of
@@ -259,23 +270,22 @@ __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int
         s_nk[cb & 1] = cnt;
       }
     }
-    // ONE barrier per block: wave 0 folds this block's kept rows into the NEXT block (its own c1 = cb + 1) as soon as it has
-    // them, so it can resolve that block right after the barrier; the other waves fold into the blocks from cb + 2 on while
-    // it does -- those words are not read before a later barrier.  (Two waves may touch one word in the same interval: LDS
-    // atomics.)
+    // ONE barrier per block: wave 0 folds this block's kept rows into the NEXT block (its own first fold, cb + 1) as soon as
+    // it has them, so it can resolve that block right after the barrier; the other waves fold into the blocks from cb + 2 on
+    // while it does -- those words are not read before a later barrier.  (Two waves may touch one word in the same interval:
+    // LDS atomics.)
     __syncthreads();
     const unsigned long long kb = s_kept[cb & 1];
     nk = s_nk[cb & 1];
     // the columns of the later blocks that one of this block's kept rows suppresses: one AND and one ballot per block
-    if (c1 < cb1) {
-      const unsigned long long h1 = ballot64((f1 & kb) != 0ull);
-      if (lane == 0 && h1 != 0ull) atomicOr(&removed[c1], h1);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+      const int c = cb + 1 + w + j * NW;
+      if (c < cb1) {
+        const unsigned long long h = ballot64((f[j] & kb) != 0ull);
+        if (lane == 0 && h != 0ull) atomicOr(&removed[c], h);
+      }
     }
-    if (c2 < cb1) {
-      const unsigned long long h2 = ballot64((f2 & kb) != 0ull);
-      if (lane == 0 && h2 != 0ull) atomicOr(&removed[c2], h2);
-    }
-    // kBandBlocks <= 32: c1 and c2 cover every later block of the band
   }
   __syncthreads();  // the last block's folds and kept indices
 
@@ -283,7 +293,7 @@ __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int
   const bool finished = (nk >= R) || last_phase || (cb1 >= nb);
   if (finished) {
     const int Ro = p.R_out;
-    for (int r = tid; r < Ro; r += 1024) {
+    for (int r = tid; r < Ro; r += NT) {
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       float sc = 0.0f;
       if (r < nk) {
@@ -305,35 +315,37 @@ __device__ __forceinline__ void bm_scan_image(const BitmaskParams &p, int b, int
       p.state[b * 4 + 1] = 1;
     }
   } else {
-    for (int i = tid; i < nb; i += 1024) p.removed[(long long)b * nb + i] = removed[i];
-    for (int i = tid; i < nk; i += 1024) p.kidx[(long long)b * R + i] = kidx[i];
+    for (int i = tid; i < nb; i += NT) p.removed[(long long)b * nb + i] = removed[i];
+    for (int i = tid; i < nk; i += NT) p.kidx[(long long)b * R + i] = kidx[i];
     if (tid == 0) p.state[b * 4 + 0] = nk;
   }
 }
 
-__global__ __launch_bounds__(1024) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void bm_scan_kernel(BitmaskParams p, int cb0, int last_phase) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
   __shared__ unsigned long long s_kept[2];  // double-buffered: wave 0 runs one block ahead of the waves that read them
   __shared__ int s_nk[2];
-  bm_scan_image(p, blockIdx.x, cb0, last_phase, s_words, s_kept, s_nk);
+  bm_scan_image<NW>(p, blockIdx.x, cb0, last_phase, s_words, s_kept, s_nk);
 }
 
 // The scan of band [cb0, ...) beside the NEXT band's own tiles, which do not depend on it: workgroups 0 .. B-1 scan, the
-// others are 16 waves with one (image, column block, row block) tile of band [nb0, nb0 + nbn) each (row block <= column
+// others are NW waves with one (image, column block, row block) tile of band [nb0, nb0 + nbn) each (row block <= column
 // block; the other half of the square returns at once).  An image that finishes in this very scan has its next-band tiles
 // computed for nothing; images finished earlier are skipped.
-__global__ __launch_bounds__(1024) void bm_scan_tiles_kernel(BitmaskParams p, int cb0, int B, int nb0, int nbn) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void bm_scan_tiles_kernel(BitmaskParams p, int cb0, int B, int nb0, int nbn) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_words[];
   __shared__ unsigned long long s_kept[2];
   __shared__ int s_nk[2];
-  __shared__ float4 s_box[16][64];
-  __shared__ float2 s_af[16][64];
+  __shared__ float4 s_box[NW][64];
+  __shared__ float2 s_af[NW][64];
   if ((int)blockIdx.x < B) {
-    bm_scan_image(p, blockIdx.x, cb0, 0, s_words, s_kept, s_nk);
+    bm_scan_image<NW>(p, blockIdx.x, cb0, 0, s_words, s_kept, s_nk);
     return;
   }
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long long t = ((long long)blockIdx.x - B) * 16 + w;
+  const long long t = ((long long)blockIdx.x - B) * NW + w;
   const int per_image = nbn * nbn;
   const int b = (int)(t / per_image);
   if (b >= B) return;
@@ -438,13 +450,14 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   rc = check_launch("roi_bbox (bitmask prepare)");
   if (rc) return rc;
   const size_t lds = (size_t)p.nb * 8 + (size_t)((R_nms + 1) & ~1) * 4 + (size_t)kBandBlocks * 64 * 8;
-  auto scan = bm_scan_kernel;
+  // FRCNN_BITMASK_THREADS = 256 | 1024: the scans' workgroup size (same results).  256 by default: see bm_scan_image.
+  const bool small_wg = knob(kKnobBitmaskThreads, 256) != 1024;
+  auto scan = small_wg ? bm_scan_kernel<4> : bm_scan_kernel<16>;
+  auto scan_tiles = small_wg ? bm_scan_tiles_kernel<4> : bm_scan_tiles_kernel<16>;
+  const int nw = small_wg ? 4 : 16;
   if (lds > 48 * 1024) {
     rc = ensure_dynamic_lds(reinterpret_cast<const void *>(scan), lds, "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
-  }
-  auto scan_tiles = bm_scan_tiles_kernel;
-  if (lds > 48 * 1024) {
     rc = ensure_dynamic_lds(reinterpret_cast<const void *>(scan_tiles), lds, "roi_bbox: hipFuncSetAttribute");
     if (rc) return rc;
   }
@@ -469,11 +482,11 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
       if (rc) return rc;
     }
     if (cb1 >= p.nb) {
-      hipLaunchKernelGGL(scan, dim3((unsigned)B), dim3(1024), lds, stream, p, cb0, 1);
+      hipLaunchKernelGGL(scan, dim3((unsigned)B), dim3((unsigned)nw * 64u), lds, stream, p, cb0, 1);
     } else {
       const int nbn = (cb1 + kBandBlocks < p.nb) ? kBandBlocks : p.nb - cb1;  // column blocks of the next band
-      const long long tile_wgs = ((long long)B * nbn * nbn + 15) / 16;
-      hipLaunchKernelGGL(scan_tiles, dim3((unsigned)(B + tile_wgs)), dim3(1024), lds, stream, p, cb0, B, cb1, nbn);
+      const long long tile_wgs = ((long long)B * nbn * nbn + nw - 1) / nw;
+      hipLaunchKernelGGL(scan_tiles, dim3((unsigned)(B + tile_wgs)), dim3((unsigned)nw * 64u), lds, stream, p, cb0, B, cb1, nbn);
     }
     rc = check_launch("roi_bbox (bitmask scan)");
     if (rc) return rc;

@@ -232,19 +232,36 @@ __device__ __forceinline__ void select_largest(KeyF keyf, int N, int S, uint32_t
 }
 
 // utils/train_utils.py:72-88, one image per workgroup.
+// rnd == NULL: the random integers are drawn in-kernel from `seed`, U[1, 10 * max(select)) as :82-83 -- the maximum over
+// the batch is taken here, on the device (every workgroup reads the n_select <= B entries), so the host never has to
+// look at `select`.
 __global__ __launch_bounds__(1024) void select_mask_kernel(const uint8_t *__restrict__ mask,
-                                                           const int *__restrict__ rnd,
+                                                           const int *__restrict__ rnd, unsigned long long seed,
                                                            const int *__restrict__ select, int n_select, int N,
                                                            uint8_t *__restrict__ out) {
   __shared__ uint32_t hist[256];
   __shared__ int misc[8];
   __shared__ int wsum[kTNW];
+  __shared__ int s_max;
   const int b = blockIdx.x;
   const uint8_t *m = mask + (long long)b * N;
-  const int *r = rnd + (long long)b * N;
   uint8_t *o = out + (long long)b * N;
   const int S = select[n_select == 1 ? 0 : b];
-  select_largest([&](int n) { return (m[n] ? 1 : 0) * r[n]; }, N, S, hist, misc, wsum,
+  if (rnd) {
+    const int *r = rnd + (long long)b * N;
+    select_largest([&](int n) { return (m[n] ? 1 : 0) * r[n]; }, N, S, hist, misc, wsum,
+                   [&](int n, bool in) { o[n] = (uint8_t)((m[n] != 0) && in); });
+    return;
+  }
+  if (threadIdx.x == 0) s_max = select[0];
+  __syncthreads();
+  int mx = select[0];
+  for (int i = threadIdx.x; i < n_select; i += kTNT) mx = (select[i] > mx) ? select[i] : mx;
+  if (mx > select[0]) atomicMax(&s_max, mx);
+  __syncthreads();
+  const long long mv = 10ll * s_max;
+  const int maxval = mv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)mv;  // (<= 1: tf.random.uniform raises; here every draw is 1 and S <= 0 selects nothing)
+  select_largest([&](int n) { return (m[n] ? 1 : 0) * draw_int(seed, 4u, b, n, maxval); }, N, S, hist, misc, wsum,
                  [&](int n, bool in) { o[n] = (uint8_t)((m[n] != 0) && in); });
 }
 
@@ -536,15 +553,26 @@ using namespace frcnn;
 
 extern "C" {
 
-int frcnn_select_mask(const uint8_t *mask, const int32_t *random_mask, const int32_t *select,
-                      int n_select, int B, int N, uint8_t *out, frcnn_stream_t stream) {
-  FRCNN_REQUIRE(mask && random_mask && select && out, "select_mask: null pointer");
+static int select_mask_impl(const uint8_t *mask, const int32_t *random_mask, uint64_t seed, const int32_t *select,
+                            int n_select, int B, int N, uint8_t *out, frcnn_stream_t stream) {
   FRCNN_REQUIRE(B >= 0 && N >= 0, "select_mask: negative shape");
   FRCNN_REQUIRE(n_select == 1 || n_select == B, "select_mask: select_xyz must have 1 or batch_size (%d) entries, got %d", B, n_select);
   if (B == 0 || N == 0) return FRCNN_OK;
   hipLaunchKernelGGL(select_mask_kernel, dim3((unsigned)B), dim3(kTNT), 0, (hipStream_t)stream, mask, random_mask,
-                     select, n_select, N, out);
+                     (unsigned long long)seed, select, n_select, N, out);
   return check_launch("select_mask");
+}
+
+int frcnn_select_mask(const uint8_t *mask, const int32_t *random_mask, const int32_t *select,
+                      int n_select, int B, int N, uint8_t *out, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(mask && random_mask && select && out, "select_mask: null pointer");
+  return select_mask_impl(mask, random_mask, 0, select, n_select, B, N, out, stream);
+}
+
+int frcnn_select_mask_seeded(const uint8_t *mask, const int32_t *select, int n_select, uint64_t seed, int B, int N,
+                             uint8_t *out, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(mask && select && out, "select_mask_seeded: null pointer");
+  return select_mask_impl(mask, nullptr, seed, select, n_select, B, N, out, stream);
 }
 
 size_t frcnn_rpn_targets_workspace_bytes(int B, int N, int M) {

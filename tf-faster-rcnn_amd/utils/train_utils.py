@@ -61,7 +61,7 @@ def get_step_size(total_items: int, batch_size: int) -> int:
 
 
 def randomly_select_xyz_mask(mask: torch.Tensor, select_xyz: Any,
-                             random_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             random_mask: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> torch.Tensor:
     """Keep up to ``select_xyz`` true elements per batch row.  Mirrors reference
     ``utils/train_utils.py:72-88``.
 
@@ -69,7 +69,9 @@ def randomly_select_xyz_mask(mask: torch.Tensor, select_xyz: Any,
     elements whose rank in the descending argsort is below ``select`` (ties: lower index first).
     TF's Philox stream cannot be reproduced, so the random integers may be passed in as
     ``random_mask`` ``(batch, total_items)`` int32 (extra, optional argument); when omitted they are
-    drawn on the device with the same range.
+    drawn in the kernel with the same range (``seed``: extra, optional; a fresh host-side draw per call
+    otherwise).  Either way the call only enqueues work: ``max(select)`` is taken on the device.  Where
+    ``tf.random.uniform`` would raise (``10*max(select) <= 1``) nothing is selected.
 
     Args:
         mask: ``(batch, total_items)`` bool.
@@ -83,20 +85,20 @@ def randomly_select_xyz_mask(mask: torch.Tensor, select_xyz: Any,
     sel = _lib.device_tensor(select_xyz, torch.int32, device).reshape(-1)
     if sel.numel() not in (1, B):
         raise ValueError(f"select_xyz must have 1 or batch_size entries, got {sel.numel()}")
-    if random_mask is None:
-        maxval = int(sel.max().item()) * 10
-        if maxval <= 1:
-            raise ValueError("Need minval < maxval, got 1 >= %d" % maxval)  # tf.random.uniform's check
-        rnd = torch.randint(1, maxval, (B, N), dtype=torch.int32, device=device)
-    else:
-        rnd = _lib.device_tensor(random_mask, torch.int32, device)
-        if rnd.shape != m.shape:
-            raise ValueError("random_mask must have the shape of mask")
     m8 = m.view(torch.uint8)
     out = torch.empty((B, N), dtype=torch.uint8, device=device)
     with _lib.on_device(device):
-        _lib.check(_lib.lib().frcnn_select_mask(_lib.ptr(m8), _lib.ptr(rnd), _lib.ptr(sel), sel.numel(), B, N,
-                                                _lib.ptr(out), _lib.stream_ptr(device)))
+        if random_mask is None:
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # host RNG: no device sync
+            _lib.check(_lib.lib().frcnn_select_mask_seeded(_lib.ptr(m8), _lib.ptr(sel), sel.numel(), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                           B, N, _lib.ptr(out), _lib.stream_ptr(device)))
+        else:
+            rnd = _lib.device_tensor(random_mask, torch.int32, device)
+            if rnd.shape != m.shape:
+                raise ValueError("random_mask must have the shape of mask")
+            _lib.check(_lib.lib().frcnn_select_mask(_lib.ptr(m8), _lib.ptr(rnd), _lib.ptr(sel), sel.numel(), B, N,
+                                                    _lib.ptr(out), _lib.stream_ptr(device)))
     return out.view(torch.bool)
 
 
@@ -207,6 +209,10 @@ def _rpn_target_batches(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tenso
             with torch.cuda.stream(side):
                 deltas, labels = calculate_rpn_actual_outputs(anchors_t, gt_t, lab_t, hyper_params, random_masks=masks,
                                                               seed=None if seed is None else seed + counter)
+            # everything the target kernels read was allocated on the caller's stream and is read on the side stream: the
+            # caching allocator must not hand those blocks out again before the side stream has passed this point
+            for t in (gt_t, lab_t) + (tuple(masks) if masks is not None else ()):
+                t.record_stream(side)
             done = _lib.HipEvent()
             done.record(side.cuda_stream)
             counter += 1
