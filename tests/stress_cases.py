@@ -14,7 +14,7 @@ import tf_faster_rcnn_amd as pkg
 
 KNOBS = ("FRCNN_CROP_SPLIT", "FRCNN_CROP_SORT", "FRCNN_CROP_PREFETCH", "FRCNN_CROP_SLICE", "FRCNN_CROP_ROWS", "FRCNN_SORT_RADIX_ONLY",
          "FRCNN_PROPOSAL_THREADS", "FRCNN_PROPOSAL_CHUNK", "FRCNN_PROPOSAL_EXACT_SLICES", "FRCNN_ROI_BBOX_BITMASK_MIN_R",
-         "FRCNN_DECODER_THREADS", "FRCNN_BITMASK_THREADS")
+         "FRCNN_DECODER_THREADS", "FRCNN_BITMASK_THREADS", "FRCNN_IOU_REDUCE_SPLIT")
 
 
 class Mismatch(AssertionError):
@@ -192,6 +192,7 @@ def _run(rng, budget, progress, max_cases):
             lo, hi = [(1, 4), (1, 2560), (3000, 4200), (-3, 60), (1, 2 ** 30)][int(rng.integers(0, 5))]
             rp = rng.integers(lo, hi, (B, N)).astype(np.int32)
             rn = rng.integers(lo, hi, (B, N)).astype(np.int32)
+            lib.set_schedule("FRCNN_IOU_REDUCE_SPLIT", int(rng.integers(0, 2)))
             gd, gl = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp, random_masks=(dev(rp), dev(rn)))
             wd, wl = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
             same(gl, wl, f"rpn labels B={B} G={G} M={M} ints=[{lo},{hi})")

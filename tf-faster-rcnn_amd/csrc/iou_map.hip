@@ -472,6 +472,10 @@ int frcnn::iou_map_reduce_impl(const float *bboxes, int bboxes_batched, const fl
     // 64 images 104 -> 83 us); FRCNN_IOU_REDUCE_SPLIT = 0 | 1 forces one form
     const bool split = knob(kKnobIouReduceSplit, M >= 8 ? 1 : 0) != 0 && M > 0 &&
                        lds_bytes + 3 * 256 * 4 <= 48 * 1024;
+    // (Tried in round 3 and removed: the per-gt argmax taken from an LDS tile of the workgroup's 64 x M quotients by a
+    // transposed pass, lane = gt, instead of the cross-lane maximum inside the pair loop -- bit-identical, 22.8 us against
+    // 20.0 at config 4's shard of 8 images: the cross-lane work only runs for the third of the (wave, gt) steps that have an
+    // overlap at all, the transposed pass reads every quotient.)
     if (split)
       hipLaunchKernelGGL(iou_reduce_split_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)B), block, lds_bytes + 3 * 256 * 4, s,
                          bboxes, stride, gt_boxes, N, M, max_iou, argmax_row, keys);

@@ -33,11 +33,30 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
-// In-kernel stand-in for tf.random.uniform(minval=1, maxval=maxval, dtype=int32) (train_utils.py:83).
-__device__ __forceinline__ int draw_int(uint64_t seed, uint32_t stream, int b, int n, int maxval) {
-  const uint64_t h = mix64(mix64(seed ^ ((uint64_t)stream << 56)) + ((uint64_t)(uint32_t)b << 32) + (uint32_t)n);
+// In-kernel stand-in for tf.random.uniform(minval=1, maxval=maxval, dtype=int32) (train_utils.py:83): a counter-based hash
+// of (seed, sampling call, image, element).  The 64-bit mixing of (seed, call, image) happens once per workgroup (DrawKey,
+// block-uniform); per element it is one 32-bit multiply-xorshift round ("lowbias32") and a multiply-high range reduction --
+// the first version mixed 64 bits twice per draw and took a modulo, and those ~160 instructions per anchor were 7 of the
+// target kernel's 32 us.
+struct DrawKey {
+  uint32_t k0, k1;
+};
+__device__ __forceinline__ DrawKey make_draw_key(uint64_t seed, uint32_t stream, int b) {
+  const uint64_t h = mix64(mix64(seed ^ ((uint64_t)stream << 56)) + (uint64_t)(uint32_t)b);
+  DrawKey k;
+  k.k0 = (uint32_t)h;
+  k.k1 = (uint32_t)(h >> 32);
+  return k;
+}
+__device__ __forceinline__ int draw_int(const DrawKey &key, int n, int maxval) {
+  uint32_t x = ((uint32_t)n ^ key.k0) * 0x9E3779B1u + key.k1;
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
   const uint32_t span = (maxval > 2) ? (uint32_t)(maxval - 1) : 1u;
-  return 1 + (int)((h >> 32) % span);
+  return 1 + (int)__umulhi(x, span);  // U[1, maxval)
 }
 
 // Workgroup-cooperative selection.  keyf(n) -> int key (= mask * random); emit(n, in) is called once
@@ -261,7 +280,8 @@ __global__ __launch_bounds__(1024) void select_mask_kernel(const uint8_t *__rest
   __syncthreads();
   const long long mv = 10ll * s_max;
   const int maxval = mv > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)mv;  // (<= 1: tf.random.uniform raises; here every draw is 1 and S <= 0 selects nothing)
-  select_largest([&](int n) { return (m[n] ? 1 : 0) * draw_int(seed, 4u, b, n, maxval); }, N, S, hist, misc, wsum,
+  const DrawKey dk = make_draw_key(seed, 4u, b);
+  select_largest([&](int n) { return (m[n] ? 1 : 0) * draw_int(dk, n, maxval); }, N, S, hist, misc, wsum,
                  [&](int n, bool in) { o[n] = (uint8_t)((m[n] != 0) && in); });
 }
 
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   const int *rp = rnd_pos ? rnd_pos + (long long)b * N : nullptr;
   const int *rn = rnd_neg ? rnd_neg + (long long)b * N : nullptr;
   auto bit = [](const uint32_t *map, int n) -> bool { return (map[n >> 5] >> (n & 31)) & 1u; };
+  const DrawKey dk_pos = make_draw_key(seed, 0u, b), dk_neg = make_draw_key(seed, 1u, b);
 
   FRCNN_STAMP(30);
   for (int i = tid; i < 3 * words; i += kTNT) maps[i] = 0u;
@@ -320,8 +341,8 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
         mi[u] = (n < N) ? miou[n] : 0.5f;
         rpv[u] = rnv[u] = 0;
         if (kcache && n < N) {
-          rpv[u] = rp ? rp[n] : draw_int(seed, 0u, b, n, 10 * total_pos);
-          rnv[u] = rn ? rn[n] : draw_int(seed, 1u, b, n, 10 * (total_pos + total_neg));
+          rpv[u] = rp ? rp[n] : draw_int(dk_pos, n, 10 * total_pos);
+          rnv[u] = rn ? rn[n] : draw_int(dk_neg, n, 10 * (total_pos + total_neg));
         }
       }
 #pragma unroll
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   // :180,:188-189 positives, sub-sampled to total_pos
   auto pos_key = [&](int n) -> int {
     if (kcache) return (int)kcache[n];  // (each thread reads the slot it then overwrites)
-    const int r = rp ? rp[n] : draw_int(seed, 0u, b, n, 10 * total_pos);
+    const int r = rp ? rp[n] : draw_int(dk_pos, n, 10 * total_pos);
     return (bit(pos_msk, n) ? 1 : 0) * r;
   };
   select_largest(pos_key, N, total_pos, hist, misc, wsum, [&](int n, bool in) {
@@ -370,7 +391,7 @@ __global__ __launch_bounds__(1024) void rpn_targets_kernel(
   // :193-194 negatives, sub-sampled to neg_count
   auto neg_key = [&](int n) -> int {
     const bool msk = bit(low_msk, n) && !bit(pos_sel, n);
-    const int r = krn ? krn[n] : (rn ? rn[n] : draw_int(seed, 1u, b, n, 10 * (total_pos + total_neg)));
+    const int r = krn ? krn[n] : (rn ? rn[n] : draw_int(dk_neg, n, 10 * (total_pos + total_neg)));
     return (msk ? 1 : 0) * r;
   };
   select_largest(neg_key, N, neg_count, hist, misc, wsum, [&](int n, bool in) {
@@ -440,12 +461,13 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
   const int *rp = rnd_pos ? rnd_pos + (long long)b * R : nullptr;
   const int *rn = rnd_neg ? rnd_neg + (long long)b * R : nullptr;
 
+  const DrawKey dk_pos = make_draw_key(seed, 2u, b), dk_neg = make_draw_key(seed, 3u, b);
   for (int i = tid; i < 2 * words; i += kTNT) maps[i] = 0u;
   __syncthreads();
   // :218-219 positives: max IoU > 0.5, sub-sampled to total_pos
   select_largest(
       [&](int n) -> int {
-        const int r = rp ? rp[n] : draw_int(seed, 2u, b, n, 10 * total_pos);
+        const int r = rp ? rp[n] : draw_int(dk_pos, n, 10 * total_pos);
         return ((miou[n] > 0.5f) ? 1 : 0) * r;
       },
       R, total_pos, hist, misc, wsum,
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(1024) void roi_delta_kernel(
   // :220-221 negatives: 0.1 < max IoU < 0.5, sub-sampled to total_neg
   select_largest(
       [&](int n) -> int {
-        const int r = rn ? rn[n] : draw_int(seed, 3u, b, n, 10 * total_neg);
+        const int r = rn ? rn[n] : draw_int(dk_neg, n, 10 * total_neg);
         return (((miou[n] < 0.5f) && (miou[n] > 0.1f)) ? 1 : 0) * r;
       },
       R, total_neg, hist, misc, wsum,

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../tf-faster-rcnn_amd/csrc"
 mkdir -p ../../tools/diag /tmp/frcnn_diag
-for f in api codec crop_resize iou_map sort_select nms nms_bitmask proposal decoder rpn_targets; do
+for f in api codec crop_resize iou_map sort_select nms nms_bitmask proposal decoder rpn_targets host_gather; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DFRCNN_STAMPS -fgpu-rdc -c $f.hip -o /tmp/frcnn_diag/$f.o &
 done
 wait
