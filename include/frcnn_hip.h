@@ -136,8 +136,9 @@ int frcnn_crop_and_resize(const float *image, int B, int H, int W, int C, const 
 /* models/faster_rcnn.py:264-293 RoIPooling.call as one entry point: RoI r of image b samples image b (:280-282),
  * bilinear crop_and_resize to (crop_h, crop_w) with extrapolation value 0 (:283-288).  feature_map (B,H,W,C); rois (B,R,4);
  * out (B,R,crop_h,crop_w,C).  Same results as frcnn_crop_and_resize(box_ind = NULL, boxes_per_image = R).  The optional
- * workspace (frcnn_roi_pooling_workspace_bytes; NULL = none) lets feature maps larger than an XCD's L2 be swept in spatial
- * order: every image's RoIs are visited top to bottom, each output still written to its own slot. */
+ * workspace (frcnn_roi_pooling_workspace_bytes; NULL = none) lets feature maps larger than an XCD's L2 (4 MiB) take the
+ * source-row-ownership schedule: the (RoI, output row) items of every image are ordered by the source row they sample and
+ * each XCD takes an eighth of that order, i.e. a band of source rows; every output is still written to its own slot. */
 size_t frcnn_roi_pooling_workspace_bytes(int B, int R);
 int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
                       int crop_h, int crop_w, float *out, void *workspace, size_t workspace_bytes,
@@ -148,11 +149,13 @@ int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, cons
  * ((B,H,W,C), (n,4), (n,ch,cw,C) each).  The reference calls the layer once per batch; a serving loop that has
  * several batches in flight (RoIPathPipeline) pays one launch tail and one inter-launch gap for all of them.
  * Results are those of `groups` frcnn_crop_and_resize calls; shapes the grouped launch is not built for are
- * executed that way. */
+ * executed that way -- for the RoIPooling layout through frcnn_roi_pooling, which is what the optional workspace
+ * (frcnn_roi_pooling_workspace_bytes(B, boxes_per_image); NULL = none) is handed to. */
 int frcnn_crop_and_resize_multi(const float *const *images, const float *const *boxes,
                                 float *const *outs, int groups, int B, int H, int W, int C, int n,
                                 int boxes_per_image, int crop_h, int crop_w,
-                                float extrapolation_value, frcnn_stream_t stream);
+                                float extrapolation_value, void *workspace, size_t workspace_bytes,
+                                frcnn_stream_t stream);
 
 /* models/faster_rcnn.py:63-91 Decoder.call, fused: per-class variance scale + decode,
  * background-argmax masking, per-class NMS, cross-class top-T.  rois (B,R,4); deltas (B,R,L*4);

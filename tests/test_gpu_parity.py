@@ -1296,14 +1296,14 @@ def test_crop_and_resize_multi_matches_oracle(pkg, groups, C, H):
     stream = torch.cuda.current_stream().cuda_stream
     _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_rois]),
                                                      arr(*[t.data_ptr() for t in outs]), groups, B, H, W, C, B * R, R, 7, 7,
-                                                     0.0, stream))
+                                                     0.0, None, 0, stream))
     torch.cuda.synchronize()
     for g in range(groups):
         assert_bits(outs[g], oracle.roi_pooling(fms[g], rois[g], (7, 7)), f"crop multi triple {g} of {groups} C={C}")
     with pytest.raises(ValueError):
         _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_rois]),
                                                          arr(*[t.data_ptr() for t in outs]), 5, B, H, W, C, B * R, R, 7, 7,
-                                                         0.0, stream))
+                                                         0.0, None, 0, stream))
 
 
 @pytest.mark.parametrize("groups,n,bpi,pf", [(4, 10, 4, 3), (3, 10, 4, 40005), (2, 37, 5, 7), (4, 97, 16, 10002)])
@@ -1326,7 +1326,7 @@ def test_crop_and_resize_multi_ragged_triples_with_warmup(pkg, knobs, groups, n,
     knobs.setenv("FRCNN_CROP_PREFETCH", pf)
     _lib.check(_lib.lib().frcnn_crop_and_resize_multi(arr(*[t.data_ptr() for t in d_fm]), arr(*[t.data_ptr() for t in d_boxes]),
                                                      arr(*[t.data_ptr() for t in outs]), groups, B, H, W, C, n, bpi, 7, 7, 0.0,
-                                                     torch.cuda.current_stream().cuda_stream))
+                                                     None, 0, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     for g in range(groups):
         assert_bits(outs[g], oracle.crop_and_resize(fms[g], boxes[g], ind, (7, 7)), f"ragged crop multi triple {g} of {groups}")

@@ -89,10 +89,10 @@ def test_multi_entry_points_validate_on_the_host():
     lib = _lib.lib()
     one = (ctypes.c_void_p * 1)(None)
     f4 = _lib.float4([0.1, 0.1, 0.2, 0.2])
-    assert lib.frcnn_crop_and_resize_multi(None, None, None, 1, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None) == _lib.FRCNN_EINVAL
-    assert lib.frcnn_crop_and_resize_multi(one, one, one, 5, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None) == _lib.FRCNN_EINVAL
+    assert lib.frcnn_crop_and_resize_multi(None, None, None, 1, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None, 0, None) == _lib.FRCNN_EINVAL
+    assert lib.frcnn_crop_and_resize_multi(one, one, one, 5, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None, 0, None) == _lib.FRCNN_EINVAL
     assert b"groups" in lib.frcnn_last_error()
-    assert lib.frcnn_crop_and_resize_multi(one, one, one, 1, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None) == _lib.FRCNN_EINVAL  # null entry
+    assert lib.frcnn_crop_and_resize_multi(one, one, one, 1, 1, 4, 4, 4, 1, 1, 7, 7, 0.0, None, 0, None) == _lib.FRCNN_EINVAL  # null entry
     assert lib.frcnn_roi_bbox_multi(one, one, None, f4, 0, 1, 9, 4, 2, 0.7, one, None, 0, None) == _lib.FRCNN_EINVAL
     assert lib.frcnn_decoder_multi(one, one, one, f4, 9, 1, 4, 3, 2, 0.5, 0.5, one, one, one, None, 0, None) == _lib.FRCNN_EINVAL
 

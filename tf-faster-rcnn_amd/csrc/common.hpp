@@ -47,6 +47,7 @@ enum Knob {
   kKnobProposalExactSlices,  // FRCNN_PROPOSAL_EXACT_SLICES 1: the fused RoIBBox kernel cuts its slices by exact rank only
   kKnobSortRadixOnly,    // FRCNN_SORT_RADIX_ONLY       1: sort_select_kernel orders its slots by the stable radix sort only
   kKnobBitmaskThreads,   // FRCNN_BITMASK_THREADS       256|1024: workgroup size of the whole-chip bitmask schedule's scan kernels
+  kKnobCropRowband,      // FRCNN_CROP_ROWBAND          0|1: frcnn_roi_pooling's source-row-ownership schedule (default: beyond 4 MiB per image)
   kKnobCount
 };
 bool knob_set(Knob k);
@@ -309,8 +310,18 @@ extern __device__ int g_nstamps;
       ++g_nstamps;                                                        \
     }                                                                     \
   } while (0)
+// the same for one chosen workgroup (`cond`: block-uniform)
+#define FRCNN_STAMP_IF(cond, tag)                                         \
+  do {                                                                    \
+    if ((cond) && threadIdx.x == 0 && g_nstamps < 127) {                  \
+      g_stamps[2 * g_nstamps] = ((long long)(tag) << 48) | ((long long)clock64() & 0xFFFFFFFFFFFFll); \
+      g_stamps[2 * g_nstamps + 1] = (long long)wall_clock64();            \
+      ++g_nstamps;                                                        \
+    }                                                                     \
+  } while (0)
 #else
 #define FRCNN_STAMP(tag) do { } while (0)
+#define FRCNN_STAMP_IF(cond, tag) do { } while (0)
 #endif
 
 // ---- wave helpers (wave = 64 lanes on gfx950) ---------------------------------------------------

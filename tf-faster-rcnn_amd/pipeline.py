@@ -251,6 +251,7 @@ class RoIPathPipeline:
                 s.host = dict(zip(names, views(s.h_small)))
         self._ws_prop = torch.empty(max(1, lib.frcnn_roi_bbox_workspace_bytes(B, N, self._K, R)), dtype=torch.uint8, device=dev)
         self._ws_dec = None if self.train else torch.empty(max(1, lib.frcnn_decoder_workspace_bytes(B, R, L, T)), dtype=torch.uint8, device=dev)
+        self._ws_pool = torch.empty(max(1, lib.frcnn_roi_pooling_workspace_bytes(B, R)), dtype=torch.uint8, device=dev)
         self._ws_prop2 = torch.empty_like(self._ws_prop) if self.train else None  # the second proposal lane's workspace
         self._ws_delta: Dict[Tuple[int, int], torch.Tensor] = {}  # train mode: RoIDelta's workspace per (gt boxes per image, lane)
         torch.cuda.synchronize(dev)
@@ -469,7 +470,8 @@ class RoIPathPipeline:
             timing[0].record(q_pool)
         if "crop" not in self._skip:
             _lib.check(lib.frcnn_crop_and_resize_multi(tab([s.pending[0] for s in slots]), own["rois"], own["pooled"],
-                                                       n, B, H, W, C, B * R, R, ph, pw, 0.0, q_pool))
+                                                       n, B, H, W, C, B * R, R, ph, pw, 0.0, self._ws_pool.data_ptr(),
+                                                       self._ws_pool.numel(), q_pool))
         if timing is not None:
             timing[1].record(q_pool)
         outs = []

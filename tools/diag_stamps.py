@@ -33,6 +33,25 @@ if len(sys.argv) >= 2 and sys.argv[1] == "decoder":  # python tools/diag_stamps.
     for i in range(n):
         print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
     sys.exit(0)
+if len(sys.argv) >= 2 and sys.argv[1] == "crop5":  # python tools/diag_stamps.py crop5  -> one mid-image workgroup of the staged-row crop (cfg5 shard)
+    B_, G_, C_, R_ = 16, 63, 576, 300
+    hp = pkg.train_utils.get_hyper_params("mobilenet_v2", feature_map_shape=G_, pre_nms_topn=12000, img_size=1000)
+    anchors = pkg.bbox_utils.generate_anchors(hp)
+    d, s = synth.rpn_outputs(0, B_, G_)
+    rois = pkg.faster_rcnn.RoIBBox(anchors, "inference", hp)([torch.as_tensor(d).cuda(), torch.as_tensor(s).cuda()])
+    fms = [torch.as_tensor(synth.feature_map(k, B_, G_, C_)).cuda() for k in range(3)]
+    pool = pkg.faster_rcnn.RoIPooling(hp)
+    buf = np.zeros(256, dtype=np.int64)
+    for it in range(4):
+        torch.cuda.synchronize()
+        lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+        pool([fms[it % 3], rois])
+        torch.cuda.synchronize()
+        n = lib.frcnn_debug_stamps(buf.ctypes.data, 1)
+    tags, t = buf[0:2 * n:2] >> 48, buf[1:2 * n:2]
+    for i in range(n):
+        print(f"tag {tags[i]:3d}  t={(t[i]-t[0])*10/1000:8.2f} us  d={(t[i]-t[i-1])*10/1000 if i else 0:8.2f} us")
+    sys.exit(0)
 if len(sys.argv) >= 2 and sys.argv[1] == "targets":  # python tools/diag_stamps.py targets [B]  -> rpn_targets_kernel's stamps (cfg4)
     B_ = int(sys.argv[2]) if len(sys.argv) >= 3 else 8
     hp = pkg.train_utils.get_hyper_params("mobilenet_v2")
