@@ -118,7 +118,8 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
  * of `groups` device pointers.  No counterpart in the reference (which calls the layer once per batch,
  * models/faster_rcnn.py:318); for serving loops that keep several batches in flight (RoIPathPipeline): the one
  * workgroup per image of `groups` batches become resident together.  Same results as `groups` frcnn_roi_bbox calls;
- * schedules without a grouped form are executed that way. */
+ * schedules without a grouped form are executed that way, with the workgroup sizes that can become resident beside a
+ * running crop launch (the whole-chip bitmask schedule's scans: 256 instead of 1024 threads). */
 int frcnn_roi_bbox_multi(const float *const *deltas, const float *const *scores, const float *anchors,
                          const float *variances, int groups, int B, int N, int K, int R,
                          float iou_threshold, float *const *out_boxes, void *workspace,

@@ -361,7 +361,7 @@ bool roi_bbox_bitmask_applies(int B, int K, int R_nms);
 size_t roi_bbox_bitmask_workspace_bytes(int B, int K, int R_nms);
 int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
                             int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
-                            int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream);
+                            int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream, bool overlapped);
 
 // decoder.hip
 int launch_decoder(const float *const *rois, const float *const *deltas, const float *const *probs, int groups,
@@ -425,10 +425,12 @@ size_t frcnn_roi_bbox_workspace_bytes(int B, int N, int K, int R) {
   return bytes;
 }
 
-int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchors,
-                   const float *variances, int B, int N, int K, int R, float iou_threshold,
-                   float *out_boxes, float *out_scores, int32_t *out_valid, void *workspace,
-                   size_t workspace_bytes, frcnn_stream_t stream) {
+// overlapped: the call comes from the grouped entry point, i.e. from a runtime that keeps several batches in flight on
+// several streams (RoIPathPipeline): schedules then prefer workgroups that can become resident beside a running crop.
+static int roi_bbox_impl(const float *deltas, const float *scores, const float *anchors,
+                         const float *variances, int B, int N, int K, int R, float iou_threshold,
+                         float *out_boxes, float *out_scores, int32_t *out_valid, void *workspace,
+                         size_t workspace_bytes, frcnn_stream_t stream, bool overlapped) {
   FRCNN_REQUIRE(deltas && scores && anchors && variances && out_boxes, "roi_bbox: null pointer");
   FRCNN_REQUIRE(B >= 0 && N > 0 && K > 0 && R >= 0, "roi_bbox: bad shape B=%d N=%d K=%d R=%d", B, N, K, R);
   FRCNN_REQUIRE(K <= N, "roi_bbox: input must have at least k columns (pre_nms_topn=%d, anchors=%d)", K, N);
@@ -444,7 +446,7 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
       // large post_nms_topn (training): the pair tests go to the whole chip (nms_bitmask.hip)
       if (roi_bbox_bitmask_applies(B, K, Rn))
         return launch_roi_bbox_bitmask(deltas, scores, anchors, variances, B, N, K, R, Rn, iou_threshold, out_boxes,
-                                       out_scores, out_valid, workspace, workspace_bytes, (hipStream_t)stream);
+                                       out_scores, out_valid, workspace, workspace_bytes, (hipStream_t)stream, overlapped);
       int rc = launch_proposal(&deltas, &scores, 1, anchors, variances, B, N, K, R, Rn, iou_threshold, &out_boxes,
                                &out_scores, &out_valid, (hipStream_t)stream, false, &handled);
       if (rc || handled) return rc;
@@ -477,6 +479,14 @@ int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchor
                       nullptr, out_valid, workspace, workspace_bytes, (hipStream_t)stream, "roi_bbox");
 }
 
+int frcnn_roi_bbox(const float *deltas, const float *scores, const float *anchors,
+                   const float *variances, int B, int N, int K, int R, float iou_threshold,
+                   float *out_boxes, float *out_scores, int32_t *out_valid, void *workspace,
+                   size_t workspace_bytes, frcnn_stream_t stream) {
+  return roi_bbox_impl(deltas, scores, anchors, variances, B, N, K, R, iou_threshold, out_boxes, out_scores, out_valid, workspace,
+                       workspace_bytes, stream, false);
+}
+
 int frcnn_roi_bbox_multi(const float *const *deltas, const float *const *scores, const float *anchors,
                          const float *variances, int groups, int B, int N, int K, int R, float iou_threshold,
                          float *const *out_boxes, void *workspace, size_t workspace_bytes, frcnn_stream_t stream) {
@@ -500,8 +510,8 @@ int frcnn_roi_bbox_multi(const float *const *deltas, const float *const *scores,
     if (rc || handled) return rc;
   }
   for (int g = 0; g < groups; ++g) {  // schedules without a grouped form: one call per batch (stream-ordered workspace reuse)
-    int rc = frcnn_roi_bbox(deltas[g], scores[g], anchors, variances, B, N, K, R, iou_threshold, out_boxes[g], nullptr,
-                            nullptr, workspace, workspace_bytes, stream);
+    int rc = roi_bbox_impl(deltas[g], scores[g], anchors, variances, B, N, K, R, iou_threshold, out_boxes[g], nullptr,
+                           nullptr, workspace, workspace_bytes, stream, true);
     if (rc) return rc;
   }
   return FRCNN_OK;

@@ -406,7 +406,7 @@ size_t roi_bbox_bitmask_workspace_bytes(int B, int K, int R_nms) { return carve_
 
 int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const float *anchors, const float *variances, int B,
                             int N, int K, int R_out, int R_nms, float iou_thr, float *out_boxes, float *out_scores,
-                            int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+                            int *out_valid, void *workspace, size_t workspace_bytes, hipStream_t stream, bool overlapped) {
   BitmaskWorkspace w = carve_bitmask(workspace, B, K, R_nms);
   if (!workspace || !aligned_to(workspace, 256) || workspace_bytes < w.bytes)
     return set_error(FRCNN_EINVAL, "roi_bbox: workspace must be non-null, 256-byte aligned and >= %zu bytes (got %zu)", w.bytes,
@@ -450,8 +450,10 @@ int launch_roi_bbox_bitmask(const float *deltas, const float *scores, const floa
   rc = check_launch("roi_bbox (bitmask prepare)");
   if (rc) return rc;
   const size_t lds = (size_t)p.nb * 8 + (size_t)((R_nms + 1) & ~1) * 4 + (size_t)kBandBlocks * 64 * 8;
-  // FRCNN_BITMASK_THREADS = 256 | 1024: the scans' workgroup size (same results).  256 by default: see bm_scan_image.
-  const bool small_wg = knob(kKnobBitmaskThreads, 256) != 1024;
+  // FRCNN_BITMASK_THREADS = 256 | 1024: the scans' workgroup size (same results).  By default 1024 for a call on its own
+  // (config 3's shard of 8 images: 148 against 203 us) and 256 when the call comes from a runtime that overlaps stages
+  // (frcnn_roi_bbox_multi): see bm_scan_image.
+  const bool small_wg = knob(kKnobBitmaskThreads, overlapped ? 256 : 1024) != 1024;
   auto scan = small_wg ? bm_scan_kernel<4> : bm_scan_kernel<16>;
   auto scan_tiles = small_wg ? bm_scan_tiles_kernel<4> : bm_scan_tiles_kernel<16>;
   const int nw = small_wg ? 4 : 16;

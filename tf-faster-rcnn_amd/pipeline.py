@@ -186,6 +186,7 @@ class RoIPathPipeline:
             self._ev_heads = [_lib.HipEvent() for _ in range(depth)]
         self._count = 0
         self._lane = 0  # train mode: the proposal lane of the next group
+        self._lanes = 1 if os.environ.get("FRCNN_PIPE_LANES") == "1" else 2  # (diagnostic: one proposal lane)
         # diagnostic ablation only (results are then wrong): FRCNN_PIPE_SKIP=prop,crop,dec leaves those launches out
         self._skip = set(filter(None, os.environ.get("FRCNN_PIPE_SKIP", "").split(",")))
         self.wait_seconds = 0.0  # host time spent blocked on back-pressure (diagnostic)
@@ -426,7 +427,7 @@ class RoIPathPipeline:
             # A lane runs proposals -> host gather of the RoIs -> RoIDelta (which needs the RoIs and the ground truth, not the
             # pooled features) in stream order, no event in between.
             lane = self._lane
-            self._lane ^= 1
+            self._lane = (self._lane + 1) % self._lanes
             q_prop = (q_prop, q_dec)[lane]
             ws_prop = self._ws_prop if lane == 0 else self._ws_prop2
         else:

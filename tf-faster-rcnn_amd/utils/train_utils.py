@@ -173,8 +173,8 @@ def _rpn_target_batches(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tenso
                         prefetch: int, seed: Optional[int],
                         random_masks: Optional[RandomMasks] = None) -> Iterator[Tuple[torch.Tensor, ...]]:
     """Endless ``(img, gt_boxes, gt_labels, bbox_deltas, bbox_labels)`` stream over ``dataset`` (re-iterated forever, as
-    the reference's ``while True``).  Target assignment for up to ``prefetch`` batches ahead is enqueued on a side HIP
-    stream, off the consumer's stream (the reference computes it eagerly on the Python feeder thread,
+    the reference's ``while True``).  Target assignment for up to ``prefetch`` batches ahead is enqueued on side HIP
+    streams (two, taken in turn, from ``prefetch = 2`` on), off the consumer's stream (the reference computes it eagerly on the Python feeder thread,
     ``utils/train_utils.py:108-112``); the consumer's current stream waits on the batch's event when it is handed over.
 
     The sampling integers of a batch (the reference draws them from TF's unseeded RNG, ``utils/train_utils.py:82-83``)
@@ -184,7 +184,9 @@ def _rpn_target_batches(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tenso
     anchors_t = _lib.device_tensor(anchors, torch.float32)
     device = anchors_t.device
     N = anchors_t.shape[0]
-    side = torch.cuda.Stream(device)
+    # with two or more batches in flight the batches alternate between two side streams: the chip-wide IoU reductions of one
+    # batch then run beside the one-workgroup-per-image target kernel of the batch before it
+    sides = [torch.cuda.Stream(device) for _ in range(2 if prefetch >= 2 else 1)]
     pending: deque = deque()
     counter = 0
     while True:
@@ -203,6 +205,7 @@ def _rpn_target_batches(dataset: Iterable[Tuple[Any, ...]], anchors: torch.Tenso
                 masks = random_masks(counter, gt_t.shape[0], N)
             if masks is not None:  # brought to the device on the caller's stream, like the gt tensors
                 masks = (_lib.device_tensor(masks[0], torch.int32, device), _lib.device_tensor(masks[1], torch.int32, device))
+            side = sides[counter % len(sides)]
             ready = _lib.HipEvent()
             ready.record(torch.cuda.current_stream(device).cuda_stream)  # the gt tensors come from the caller's stream
             ready.wait(side.cuda_stream)
