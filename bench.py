@@ -429,6 +429,9 @@ def main() -> int:
     ap.add_argument("--dump-gather", default=None,
                     help="configs 3-5: rank 0 saves the gathered host arrays of the last step (npz, with the seed of its input "
                          "set) -- what tests/test_gpu_dist.py compares with the oracle")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group (and use its barrier / all-reduce) even with one rank: lets a 1-GPU box run "
+                         "the RCCL branch of the N-rank path")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="do not time config 1, the per-GPU shards of configs 3-5 and the materialised IoU map after the headline")
     args = ap.parse_args()
@@ -447,9 +450,13 @@ def main() -> int:
     dist = None
     backend = args.dist_backend
     backend_note = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --force-dist from a plain shell: a one-rank group
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl" and (world > n_dev or args.device is not None):
             backend, backend_note = "gloo", "ranks share a GPU: RCCL needs one device per rank, barrier/max over gloo instead"
         torch.cuda.set_device(dev_index)

@@ -79,3 +79,16 @@ def test_two_ranks_weak_scaling_headline(tmp_path):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["global_batch"] == 32
     assert res["config"]["devices"] == [0, 0] and "cpu_baseline" not in res and res["value"] > 0
+
+
+def test_one_rank_over_rccl(tmp_path):
+    """The RCCL branch of the N-rank path (process group "nccl" on the rank's own device, barrier, max-over-ranks all-reduce on
+    the device, all_gather_object) with the one rank a 1-GPU box can give it: config 4's shard through the shared host gather."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--config", "4", "--batch", "8", "--steps", "5", "--warmup", "2",
+           "--blocks", "2", "--no-cpu-baseline", "--spin-up-ms", "0"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["config"]["dist_backend"] == "nccl" and res["config"]["world_size_observed"] == 1 and res["value"] > 0
+    assert res["blocks"]["ms_per_step_each"] == res["blocks"]["ms_per_step_each_fastest_rank"]  # one rank: max == min

@@ -189,9 +189,10 @@ def test_fuzz_roi_pooling_source_row_ownership(pkg, knobs):
     grouped entry point with a workspace takes the same route.  Bit-exact: every output lands in its own slot."""
     rng = np.random.default_rng(29)
     lib = pkg._lib.lib()
-    for case in range(120):
-        # 1: the taps gathered from L2 (row bands per XCD); 2: the source-row pair staged in LDS (the default form)
-        knobs.setenv("FRCNN_CROP_ROWBAND", 1 + case % 2)
+    for case in range(150):
+        # 1: the taps gathered from L2 (row bands per XCD); 2: a source-row pair staged in LDS per workgroup; 3: a strip of rows
+        # streamed through LDS by a workgroup with loader waves
+        knobs.setenv("FRCNN_CROP_ROWBAND", 1 + case % 3)
         B = int(rng.integers(1, 7))
         H, W = int(rng.integers(1, 40)), int(rng.integers(1, 14))
         C = int(rng.choice([4, 8, 12, 36, 64, 576, 1024]))

@@ -706,6 +706,165 @@ __global__ __launch_bounds__(NT) void crop_resize_rowstage_kernel(const float *_
   }
 }
 
+// ---- the same, streamed: a strip per workgroup, the loads on their own waves -------------------------------------------------
+// crop_resize_rowstage_kernel stages a row pair, produces its items and ends: while its rows travel (8-9 us for 145 KB: the
+// CU's outstanding-miss budget against the fabric's latency) the CU stores nothing, and on gfx9 a wave that has issued
+// stores cannot wait for a later load without waiting for the stores' acknowledgements too (one in-order vmcnt).  Here a
+// workgroup walks one of the image's item-balanced STRIPS of rows top to bottom with FOUR row buffers (row r in buffer
+// r % 4) and two record buffers, and the waves are specialised:
+//   waves 15 / 14 load the even / odd rows (global_load_lds; row t + 3 is requested when the pair (t, t + 1) starts and
+//                  awaited when the pair (t + 1, t + 2) ends: two pairs of slack, and a loader never has two rows in flight,
+//                  so its wait is a plain vmcnt(0)),
+//   wave 13        loads records (global_load_lds; the next step's chunk of per-pixel records),
+//   waves 0-12     compute (taps and records from LDS, nontemporal stores; they never wait on vmcnt).
+// One s_barrier per step (a chunk of <= ic items of one row pair); every wave runs the same step sequence.  Every source row
+// travels to the CU once per channel part (three more at a strip boundary).
+// LDS: 4 * W * CQ float4 of rows | 2 * ic * cw StageRec | H + 2 ints (the image's rowstart).
+__global__ __launch_bounds__(1024) void crop_resize_rowstream_kernel(const float *__restrict__ image, int B, int H, int W, int C,
+                                                                     const StageRec *__restrict__ rec,
+                                                                     const int *__restrict__ rowstart,
+                                                                     const int *__restrict__ strips, int R, int ch, int cw,
+                                                                     float extrap, float *__restrict__ out, int Q, int NS, int ic) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 rows[];
+  constexpr int kComputeWaves = 13, NTC = kComputeWaves * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = blockIdx.x % Q;
+  const int k = (blockIdx.x / Q) % NS;
+  const int b = blockIdx.x / (Q * NS);
+  if (b >= B) return;
+  const int n = R * ch;
+  const int CV = C >> 2, CQ = CV / Q;
+  const int rowlen = W * CQ;
+  const int chunk = ic * cw;  // pixels per step
+  StageRec *recbuf = reinterpret_cast<StageRec *>(rows + 4 * rowlen);  // [2][chunk]
+  int *rs = reinterpret_cast<int *>(recbuf + 2 * chunk);               // [H + 2]
+  const int t_begin = strips[(long long)b * 16 + k], t_end = strips[(long long)b * 16 + k + 1];  // rows [t_begin, t_end), t_end <= H + 1
+  if (t_begin >= t_end) return;
+  const StageRec *recs = rec + (long long)b * n * cw;  // the image's records, in rank order
+  f32x4 *__restrict__ out4 = reinterpret_cast<f32x4 *>(out);
+  const int row_wave = 15 - 0;  // even rows; odd rows: wave 14
+
+  auto load_row = [&](int r) {  // row r of this image, channel part q -> buffer r % 4 (64 lanes, 16 bytes each per trip)
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(image + ((long long)b * H + r) * W * C) + q * CQ;
+    f32x4 *dst = rows + (r & 3) * rowlen;
+    for (int j0 = 0; j0 < rowlen; j0 += 64) {
+      const int j = j0 + lane;
+      if (j < rowlen) {
+        const int col = j / CQ, c = j - col * CQ;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((long long)col * CV + c)),
+                                         (__attribute__((address_space(3))) void *)(dst + j0), 16, 0, 0);
+      }
+    }
+  };
+  auto is_loader_of = [&](int r) { return wave == row_wave - (r & 1); };
+  auto load_recs = [&](int first_pixel, int count, int buf) {  // wave 13: `count` records from first_pixel -> recbuf[buf]
+    StageRec *dst = recbuf + buf * chunk;
+    for (int j0 = 0; j0 < count; j0 += 64) {
+      if (j0 + lane < count)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(recs + first_pixel + j0 + lane),
+                                         (__attribute__((address_space(3))) void *)(dst + j0), 16, 0, 0);
+    }
+  };
+  auto step_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  // prologue: the image's rowstart (every wave needs it to follow the step sequence), the first rows, the first chunk
+  for (int i = tid; i < H + 2; i += 1024) rs[i] = rowstart[(long long)b * (H + 2) + i];
+  if (wave >= 14) {
+    for (int r = t_begin; r < t_begin + 3; ++r)  // rows t, t + 1 of the first pair and the bot row of the second
+      if (r < H && (r == t_begin || r <= t_end) && is_loader_of(r)) load_row(r);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();  // rs (nothing has been stored yet: the full barrier costs nothing here)
+  if (wave == 13) {
+    const int r0 = rs[t_begin], r1 = rs[t_begin + 1];
+    const int np = ((r1 - r0) * cw < chunk) ? (r1 - r0) * cw : chunk;
+    load_recs(r0 * cw, np, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  step_barrier();
+
+  int step = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const int r0 = rs[t], r1 = rs[t + 1];
+    const int npix = (r1 - r0) * cw;
+    const int nsteps = npix > 0 ? (npix + chunk - 1) / chunk : 1;  // a row nobody samples is one empty step
+    const unsigned topbase = (unsigned)((t & 3) * rowlen), botbase = (unsigned)(((t + 1) & 3) * rowlen);
+    for (int sidx = 0; sidx < nsteps; ++sidx, ++step) {
+      const int p0 = sidx * chunk;
+      const int np = (npix - p0 < chunk) ? (npix - p0) : chunk;  // (<= 0 for the empty step)
+      const bool last = sidx + 1 == nsteps;
+      FRCNN_STAMP_IF((b == B / 2) && (k == NS / 2) && (q == 0), 70 + (np > 0 ? (r1 - r0 > 99 ? 9 : (r1 - r0) / 11) : 0));
+      if (wave >= 14) {
+        // row t + 3 (the bot row of the pair after next) into the buffer of row t - 1, which nobody reads any more
+        if (sidx == 0 && t + 3 < H && t + 2 < t_end && is_loader_of(t + 3)) load_row(t + 3);
+        // row t + 2, requested a pair ago by this wave, must be there when the next pair starts
+        if (last && is_loader_of(t + 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (wave == 13) {
+        // the next step's records (this pair's next chunk, or the next pair's first) into the other buffer
+        int nf = -1, nc = 0;
+        if (!last) {
+          nf = r0 * cw + p0 + chunk;
+          nc = (npix - p0 - chunk < chunk) ? (npix - p0 - chunk) : chunk;
+        } else if (t + 1 < t_end) {
+          const int q0 = rs[t + 1], q1 = rs[t + 2];
+          nf = q0 * cw;
+          nc = ((q1 - q0) * cw < chunk) ? (q1 - q0) * cw : chunk;
+        }
+        if (nc > 0) load_recs(nf, nc, (step + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (np > 0) {
+        const StageRec *rb = recbuf + (step & 1) * chunk;
+        const int total = np * CQ;
+        int p = tid / CQ;
+        int c = tid - p * CQ;
+        const int dp = NTC / CQ, dcc = NTC - dp * CQ;
+        for (int e0 = tid; e0 < total; e0 += NTC * 4) {
+          f32x4 v[4];
+          unsigned at[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool in = e0 + u * NTC < total;
+            const StageRec rc = rb[in ? p : 0];
+            const unsigned cc = in ? (unsigned)c : 0u;
+            const unsigned left = (rc.bits & 1023u) * (unsigned)CQ, right = ((rc.bits >> 10) & 1023u) * (unsigned)CQ;
+            const unsigned bb = ((rc.bits >> 20) & 1u) ? topbase : botbase;  // bot == top when in_y is integral
+            // the three lerps of bilerp(), one rounding per operation, taps from LDS
+            const f32x4 tl = rows[topbase + left + cc], tr = rows[topbase + right + cc], bl = rows[bb + left + cc],
+                        br = rows[bb + right + cc];
+            f32x4 tt = vsub(tr, tl);
+            tt = tt * rc.lx;
+            const f32x4 tp = tl + tt;
+            tt = vsub(br, bl);
+            tt = tt * rc.lx;
+            const f32x4 bt = bl + tt;
+            tt = vsub(bt, tp);
+            tt = tt * rc.ly;
+            f32x4 val = tp + tt;
+            if (!((rc.bits >> 21) & 1u)) val = (f32x4)(extrap);
+            v[u] = val;
+            at[u] = (unsigned)(rc.dst + q * CQ) + cc;
+            c += dcc;
+            p += dp;
+            if (c >= CQ) {
+              c -= CQ;
+              ++p;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (e0 + u * NTC < total) __builtin_nontemporal_store(v[u], out4 + at[u]);
+        }
+      }
+      FRCNN_STAMP_IF((b == B / 2) && (k == NS / 2) && (q == 0), 80);
+      step_barrier();
+    }
+  }
+}
+
 #ifndef FRCNN_CROP_WAVES_PER_EU
 #define FRCNN_CROP_WAVES_PER_EU 4
 #endif
@@ -994,7 +1153,7 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
       const int CV = C / 4;
       int Q = 0;
       size_t stage_lds = 0;
-      const int q_forced = rb == 2 ? knob(kKnobCropSplit, 0) : 0;  // (diagnostic: FRCNN_CROP_SPLIT = Q with FRCNN_CROP_ROWBAND = 2)
+      const int q_forced = rb >= 2 ? knob(kKnobCropSplit, 0) : 0;  // (diagnostic: FRCNN_CROP_SPLIT = Q with FRCNN_CROP_ROWBAND = 2)
       for (int cand = 1; cand <= 8 && ic > 0 && crop_h * crop_w <= kStageMaxPixels && W <= 1023; cand *= 2) {
         if (CV % cand || cand < q_forced) continue;
         const size_t need = (size_t)2 * W * (CV / cand) * 16 + (size_t)ic * crop_w * sizeof(PixParam);
@@ -1004,16 +1163,38 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
           break;
         }
       }
-      const bool stage = Q > 0 && (rb >= 0 ? rb == 2 : true);
+      // the streamed form: four row buffers, two record buffers and the image's rowstart
+      int Qs = 0;
+      size_t stream_lds = 0;
+      for (int cand = 1; cand <= 8 && ic > 0 && Q > 0; cand *= 2) {
+        if (CV % cand || cand < q_forced) continue;
+        const size_t need = (size_t)4 * W * (CV / cand) * 16 + (size_t)2 * ic * crop_w * sizeof(StageRec) + (size_t)(H + 2) * 4 + 16;
+        if (need <= 160 * 1024) {
+          Qs = cand;
+          stream_lds = need;
+          break;
+        }
+      }
+      const bool stage = Q > 0 && (rb >= 0 ? (rb == 2 || (rb == 3 && Qs > 0)) : true);
       // strips per image: FRCNN_CROP_PREFETCH = n (1..15) makes a workgroup walk one of n item-balanced strips of rows with a
       // sliding two-row window instead (diagnostic)
       int NS = 0;  // one row pair per workgroup by default (measured below)
+      if (rb == 3 && Qs > 0) NS = (256 + B * Qs - 1) / (B * Qs);  // the streamed form: one strip per CU
       if (knob(kKnobCropPrefetch, -1) > 0) NS = knob(kKnobCropPrefetch, -1);
       if (NS > 15) NS = 15;
+      if (rb == 3 && NS < 1) NS = 1;
       hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, rois, R, H, crop_h, order, bounds, rowstart,
                          stage ? rec : (StageRec *)nullptr, W, crop_w, CV, NS);
       int rc = check_launch("roi_pooling (row order)");
       if (rc) return rc;
+      if (stage && rb == 3) {  // the streamed form (crop_resize_rowstream_kernel)
+        auto skern = crop_resize_rowstream_kernel;
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), stream_lds, "roi_pooling: hipFuncSetAttribute");
+        if (rc) return rc;
+        hipLaunchKernelGGL(skern, dim3((unsigned)(B * Qs * NS)), dim3(1024), stream_lds, (hipStream_t)stream, feature_map, B, H, W, C,
+                           rec, rowstart, bounds, R, crop_h, crop_w, 0.0f, out, Qs, NS, ic);
+        return check_launch("roi_pooling (streamed rows)");
+      }
       if (stage) {
         auto skern = crop_resize_rowstage_kernel<1024>;
         if (stage_lds > 48 * 1024) {
