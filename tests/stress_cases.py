@@ -14,7 +14,7 @@ import tf_faster_rcnn_amd as pkg
 
 KNOBS = ("FRCNN_CROP_SPLIT", "FRCNN_CROP_SORT", "FRCNN_CROP_PREFETCH", "FRCNN_CROP_SLICE", "FRCNN_CROP_ROWS", "FRCNN_SORT_RADIX_ONLY",
          "FRCNN_PROPOSAL_THREADS", "FRCNN_PROPOSAL_CHUNK", "FRCNN_PROPOSAL_EXACT_SLICES", "FRCNN_ROI_BBOX_BITMASK_MIN_R",
-         "FRCNN_DECODER_THREADS", "FRCNN_BITMASK_THREADS", "FRCNN_IOU_REDUCE_SPLIT", "FRCNN_CROP_ROWBAND")
+         "FRCNN_DECODER_THREADS", "FRCNN_BITMASK_THREADS", "FRCNN_IOU_REDUCE_SPLIT", "FRCNN_CROP_STAGE")
 
 
 class Mismatch(AssertionError):
@@ -101,7 +101,7 @@ def _run(rng, budget, progress, max_cases):
             ph, pw = int(rng.integers(1, 9)), int(rng.integers(1, 9))
             for name, val in (("FRCNN_CROP_SPLIT", rng.choice([-1, 0, 2, 4, 8])), ("FRCNN_CROP_SORT", rng.integers(0, 2)),
                               ("FRCNN_CROP_PREFETCH", rng.choice([-1, 0, 7, 32, 640032])), ("FRCNN_CROP_SLICE", rng.choice([-1, 0, 1])),
-                              ("FRCNN_CROP_ROWS", rng.choice([-1, 0, 1])), ("FRCNN_CROP_ROWBAND", rng.choice([-1, 0, 1, 2, 3]))):
+                              ("FRCNN_CROP_ROWS", rng.choice([-1, 0, 1])), ("FRCNN_CROP_STAGE", rng.choice([-1, 0, 1]))):
                 lib.set_schedule(name, None if val < 0 else int(val))
             fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
             rois = rng.uniform(-0.2, 1.2, (B, R, 4)).astype(np.float32)

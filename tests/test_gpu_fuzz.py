@@ -182,28 +182,31 @@ def test_fuzz_roi_pooling_sorted_channel_split(pkg, knobs):
         assert_bits(got, want, f"RoIPooling split case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw})")
 
 
-def test_fuzz_roi_pooling_source_row_ownership(pkg, knobs):
+def test_fuzz_roi_pooling_staged_rows(pkg, knobs):
     """frcnn_roi_pooling's schedule for feature maps beyond an XCD's L2 (the (RoI, output row) items of every image ordered by
-    the source row they sample, an eighth of the order per XCD, warm-up workgroups one image ahead), forced on small shapes:
-    out-of-range rows (no taps, sorted last), fewer items than XCDs, one source row, NaN boxes, every warm-up count; the
-    grouped entry point with a workspace takes the same route.  Bit-exact: every output lands in its own slot."""
+    the source row they sample, a workgroup per source-row pair and channel part with the two rows staged in LDS by
+    global_load_lds), forced on small shapes: out-of-range rows (no taps, sorted last), a single source row, rows nobody
+    samples, NaN boxes, several parameter chunks per row pair, every number of channel parts; the grouped entry point with a
+    workspace takes the same route.  Bit-exact: every output lands in its own slot."""
     rng = np.random.default_rng(29)
     lib = pkg._lib.lib()
-    for case in range(150):
-        # 1: the taps gathered from L2 (row bands per XCD); 2: a source-row pair staged in LDS per workgroup; 3: a strip of rows
-        # streamed through LDS by a workgroup with loader waves
-        knobs.setenv("FRCNN_CROP_ROWBAND", 1 + case % 3)
+    knobs.setenv("FRCNN_CROP_STAGE", 1)
+    for case in range(120):
         B = int(rng.integers(1, 7))
         H, W = int(rng.integers(1, 40)), int(rng.integers(1, 14))
         C = int(rng.choice([4, 8, 12, 36, 64, 576, 1024]))
         R = int(rng.choice([1, 2, 3, 17, 64, 300, 1025]))
         ph, pw = int(rng.integers(1, 9)), int(rng.integers(1, 5))
-        knobs.setenv("FRCNN_CROP_PREFETCH", int(rng.choice([0, 1, 3, 16, 200, 2030004])))
+        q_min = int(rng.choice([0, 0, 2, 4, 8]))  # a minimum number of channel parts (0: the fewest that fit)
+        if q_min:
+            knobs.setenv("FRCNN_CROP_SPLIT", q_min)
+        else:
+            knobs.delenv("FRCNN_CROP_SPLIT")
         fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
         lo, hi = [(-0.2, 1.2), (0.0, 1.0), (-2.0, 3.0), (0.4, 0.6)][case % 4]
         rois = rng.uniform(lo, hi, (B, R, 4)).astype(np.float32)
         if case % 5 == 0:
-            rois[0, : R // 2] = rois[0, 0]  # many items on one source row
+            rois[0, : R // 2] = rois[0, 0]  # many items on one source row: several chunks of parameters
         if case % 7 == 0:
             rois[-1, -1, 0] = np.nan  # in_y = NaN: a row without taps
         if case % 11 == 0:
@@ -211,8 +214,8 @@ def test_fuzz_roi_pooling_source_row_ownership(pkg, knobs):
         hp = synth.hyper_params(pooling_size=(ph, pw))
         want = oracle.roi_pooling(fm, rois, (ph, pw))
         got = pkg.faster_rcnn.RoIPooling(hp)([dev(fm), dev(rois)])
-        assert_bits(got, want, f"RoIPooling row-band case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw})")
-        if case % 4 == 0 and C % 4 == 0:  # the grouped entry point, a shape it hands to frcnn_roi_pooling (C % 4 != 0 or forced knobs)
+        assert_bits(got, want, f"RoIPooling staged-rows case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw}) Q>={q_min}")
+        if case % 4 == 0 and C % 4 == 0:  # the grouped entry point hands the RoIPooling layout to frcnn_roi_pooling when a knob is forced
             g = 1 + case % 3
             fms, rs = [dev(fm) for _ in range(g)], [dev(rois) for _ in range(g)]
             outs = [torch.full((B, R, ph, pw, C), float("nan"), device="cuda") for _ in range(g)]
@@ -223,7 +226,7 @@ def test_fuzz_roi_pooling_source_row_ownership(pkg, knobs):
                                                            ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
             knobs.delenv("FRCNN_CROP_ROWS")
             for o in outs:
-                assert_bits(o, want, f"grouped RoIPooling row-band case {case}: g={g}")
+                assert_bits(o, want, f"grouped RoIPooling staged-rows case {case}: g={g}")
 
 
 def test_fuzz_decoder(pkg, knobs):

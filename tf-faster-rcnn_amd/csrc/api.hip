@@ -61,7 +61,7 @@ static const char *const kKnobNames[kKnobCount] = {
     "FRCNN_CROP_SLICE",       "FRCNN_CROP_ROWS",       "FRCNN_DECODER_THREADS",
     "FRCNN_ROI_BBOX_UNFUSED", "FRCNN_DECODER_UNFUSED", "FRCNN_ROI_BBOX_BITMASK_MIN_R",
     "FRCNN_PROPOSAL_CHUNK",   "FRCNN_PROPOSAL_THREADS", "FRCNN_IOU_TILE", "FRCNN_IOU_MAP_FLAT", "FRCNN_CROP_PREFETCH", "FRCNN_CROP_SPLIT", "FRCNN_CROP_SORT", "FRCNN_IOU_REDUCE_SPLIT",
-    "FRCNN_PROPOSAL_EXACT_SLICES", "FRCNN_SORT_RADIX_ONLY", "FRCNN_BITMASK_THREADS", "FRCNN_CROP_ROWBAND"};
+    "FRCNN_PROPOSAL_EXACT_SLICES", "FRCNN_SORT_RADIX_ONLY", "FRCNN_BITMASK_THREADS", "FRCNN_CROP_STAGE"};
 
 struct KnobTable {
   std::atomic<int> value[kKnobCount];

@@ -47,7 +47,7 @@ enum Knob {
   kKnobProposalExactSlices,  // FRCNN_PROPOSAL_EXACT_SLICES 1: the fused RoIBBox kernel cuts its slices by exact rank only
   kKnobSortRadixOnly,    // FRCNN_SORT_RADIX_ONLY       1: sort_select_kernel orders its slots by the stable radix sort only
   kKnobBitmaskThreads,   // FRCNN_BITMASK_THREADS       256|1024: workgroup size of the whole-chip bitmask schedule's scan kernels
-  kKnobCropRowband,      // FRCNN_CROP_ROWBAND          0|1: frcnn_roi_pooling's source-row-ownership schedule (default: beyond 4 MiB per image)
+  kKnobCropStage,        // FRCNN_CROP_STAGE            0|1: frcnn_roi_pooling's LDS-staged-rows schedule (default: beyond 4 MiB per image)
   kKnobCount
 };
 bool knob_set(Knob k);

@@ -307,39 +307,45 @@ __global__ __launch_bounds__(256) void roi_order_kernel(const float *__restrict_
   }
 }
 
-// ---- source-row ownership (feature maps beyond an XCD's L2) ---------------------------------------------------------------
-// An output row of a box samples exactly two source rows (top, bot = top + 1).  The B*R*ch (box, output row) items of a
-// launch are ordered per image by `top` (crop_rows_order_kernel: one counting sort per image) and XCD g takes the g-th
-// eighth of every image's sorted list: all eight XCDs work on the SAME image, each on its own band of source rows, so an
-// XCD's L2 holds about an eighth of an image's rows with all their channels (1.1 MB at 63x63x576) instead of a slice of
-// the channels of all rows, every workgroup writes one contiguous run of cw*C floats (16 KB), and a feature-map byte is
-// fetched from HBM by one XCD only (plus the row both neighbours share).  The split is by item COUNT, not by row number:
-// every XCD gets the same number of items per image whatever the RoIs' spatial distribution.  Warm-up workgroups stream the
-// NEXT image's band of rows (a contiguous byte range in NHWC) into the L2 while the current image's items are written.
+// ---- LDS-staged feature rows (feature maps beyond an XCD's L2) -----------------------------------------------------------
+// With feature maps this large the RoIs span many source pixels, no two output pixels of a crop share a tap, and the tap
+// gather -- four 16-byte loads per 16 bytes written, every one of them an L1 miss -- runs into the L2's bandwidth: at
+// config 5 the taps alone take as long as the stores alone (110 us each, 165-175 together, whatever the schedule: channel
+// slices per XCD, or a band of source rows per XCD, which brought FETCH_SIZE from 2.35x to 1.25x the feature maps and did
+// not change the time).  But the 300 RoIs of an image overlap: every source pixel is sampled about 240 times.  So the
+// roles are turned round.  An output row of a box samples exactly two source rows (top, bot = top + 1).  A pre-pass
+// (crop_rows_order_kernel, one counting sort per image) orders the image's R * ch (box, output row) items by top and
+// writes every output pixel's sampling parameters in that order; then a workgroup owns a source-row pair (t, t + 1) of one
+// image and one part of the channels, stages those two rows in LDS ONCE -- straight from global memory
+// (global_load_lds: no registers; the LDS destination of such a load is wave-uniform base + lane * 16, which is rows[j]
+// for j = the wave's first j + lane) -- and produces every item of the image whose top row is t with its taps read from
+// LDS: 0.55 bytes through the L2 per byte written instead of 4.  The channels are cut into the fewest parts Q with which two
+// rows fit the LDS: an item's output is cw runs of C / Q floats (1152 B at config 5: nine full lines).
 //
-// order[b*n + rank] = item (r*ch + y) of image b at that rank of the top order (rows whose in_y is out of range carry no
-// taps and sort last); bounds[(b*8 + g)*2 + {0,1}] = first / last source row XCD g samples in image b (first > last: none).
-// One workgroup of 1024 threads per image; LDS: (H + 2) bins | n tops (uint16) | 16 wave sums.
-// rowstart[b*(H + 2) + t] = rank of the first item of image b whose top is t (t = H: the rows without taps; t = H + 1: n).
-// rec (optional): the sampling parameters of every output pixel in rank order, rec[(b*n + rank)*cw + x], for the kernel that
-// stages source rows in LDS: one coalesced 16-byte load per pixel there instead of item -> box -> coordinates.
+// Measured alternatives, all bit-identical (config 5's shard, 16 images, cold inputs; this kernel: 153 us): two workgroups
+// per CU with Q = 4 so that one loads while the other computes: 163 (576-byte runs); a workgroup walking an item-balanced
+// strip of rows with a sliding two-row window (every row loaded once): 170 -- on gfx9 a wave that has issued stores cannot
+// wait for a later load without waiting for the stores' acknowledgements (one in-order vmcnt), so each row costs a full
+// drain; the same strip walk with specialised waves (two row-loader waves, a record-loader wave, thirteen compute waves
+// that never wait on vmcnt, four row buffers, one s_barrier per row): 177 -- the loaders' requests queue behind the CU's
+// own stores in its one in-order memory pipeline, and the barrier couples the store stream to them.
 struct __attribute__((aligned(16))) StageRec {
   int dst;        // position of the pixel's C floats in the output, in float4 units
   float lx, ly;
   unsigned bits;  // left | right << 10 | (bot == top) << 20 | valid << 21   (columns < 1024)
 };
 
-__global__ __launch_bounds__(1024) void crop_rows_order_kernel(const float *__restrict__ boxes, int R, int H, int ch,
-                                                               int *__restrict__ order, int *__restrict__ bounds,
-                                                               int *__restrict__ rowstart, StageRec *__restrict__ rec, int W,
-                                                               int cw, int CV, int NS) {
+// One workgroup of 1024 threads per image.  rowstart[b*(H + 2) + t] = rank of the first item of image b whose top row is t
+// (t = H: the rows whose in_y is out of range -- no taps, sorted last; t = H + 1: n = R * ch); rec[(b*n + rank)*cw + x] = the
+// parameters of output pixel x of the item at that rank.  LDS: 1024 + 8 bins | 16 wave sums | n tops (uint16).
+__global__ __launch_bounds__(1024) void crop_rows_order_kernel(const float *__restrict__ boxes, int R, int H, int W, int ch, int cw,
+                                                               int CV, int *__restrict__ rowstart, StageRec *__restrict__ rec) {
   extern __shared__ __attribute__((aligned(16))) int sm[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = R * ch;
-  int *bins = sm;                                                  // [H + 1] counts, then running cursors
-  int *wsum = sm + 1024 + 8;                                       // [16]
-  unsigned short *tops = reinterpret_cast<unsigned short *>(wsum + 16);  // [n] top of item i, then top at rank
-  unsigned short *sorted = tops + ((n + 1) & ~1);                  // [n]
+  int *bins = sm;                                                         // [H + 1] counts, then running cursors
+  int *wsum = sm + 1024 + 8;                                              // [16]
+  unsigned short *tops = reinterpret_cast<unsigned short *>(wsum + 16);  // [n] top of item i
   for (int i = tid; i <= H; i += 1024) bins[i] = 0;
   __syncthreads();
   const float hm1 = (float)(H - 1);
@@ -381,487 +387,151 @@ __global__ __launch_bounds__(1024) void crop_rows_order_kernel(const float *__re
   __syncthreads();
   for (int i = tid; i < n; i += 1024) {
     const int top = tops[i];
-    const int pos = atomicAdd(&bins[top], 1);  // (any order inside one source row: it only decides which workgroup writes first)
-    order[(long long)b * n + pos] = i;
-    sorted[pos] = (unsigned short)top;
-    if (rec) {
-      const int r = i / ch, y = i - r * ch;
-      const long long box = (long long)b * R + r;
-      const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + box * 4);
-      StageRec *out_rec = rec + ((long long)b * n + pos) * cw;
-      for (int x = 0; x < cw; ++x) {
-        const PixParam prm = pix_param(y * cw + x, H, W, 1u, ch, cw, bx.x, bx.y, bx.z, bx.w, true);  // offsets in pixels
-        StageRec o;
-        o.dst = (int)(((box * ch + y) * cw + x) * CV);
-        o.lx = prm.lx;
-        o.ly = prm.ly;
-        o.bits = 0u;
-        if (prm.valid) {  // (then top is this item's top: the same expression)
-          const unsigned left = prm.off_tl - (unsigned)top * (unsigned)W, right = prm.off_tr - (unsigned)top * (unsigned)W;
-          o.bits = left | (right << 10) | ((prm.off_bl == prm.off_tl ? 1u : 0u) << 20) | (1u << 21);
-        }
-        out_rec[x] = o;
-      }
-    }
-  }
-  __syncthreads();
-  if (rec) {
-    // strips for the staged-row kernel: NS runs of consecutive source rows with about n / NS items each; strip k starts at
-    // the first row whose items begin at or after rank k * n / NS (bounds[b*16 + k], k = 0 .. NS <= 15; row H + 1 = the end)
-    if (tid <= NS) {
-      int tk = H + 1;
-      if (tid < NS) {
-        const int target = (int)(((long long)tid * n) / NS);
-        int lo = 0, hi = H + 1;  // smallest t with rowstart(t) >= target; rowstart(t) = end of bin t - 1 after the placement
-        while (lo < hi) {
-          const int m = (lo + hi) >> 1;
-          const int rs = (m == 0) ? 0 : bins[m - 1];
-          if (rs >= target) hi = m; else lo = m + 1;
-        }
-        tk = lo;
-      }
-      bounds[(long long)b * 16 + tid] = tk;
-    }
-    return;
-  }
-  if (tid < 8) {
-    const int per = (n + 7) >> 3;
-    const int lo = tid * per;
-    int hi = lo + per;
-    if (hi > n) hi = n;
-    int row_lo = 1, row_hi = 0;  // empty
-    if (lo < hi && sorted[lo] < H) {
-      row_lo = sorted[lo];
-      int k = hi - 1;
-      row_hi = sorted[k];
-      if (row_hi >= H) {  // the share ends in rows without taps: the last row that has some (binary search, tops ascend)
-        int a = lo, c = k;  // sorted[a] < H <= sorted[c]
-        while (c - a > 1) {
-          const int m = (a + c) >> 1;
-          if (sorted[m] < H) a = m; else c = m;
-        }
-        row_hi = sorted[a];
-      }
-      row_hi = (row_hi + 1 < H) ? row_hi + 1 : H - 1;  // bot = top + 1
-    }
-    bounds[((long long)b * 8 + tid) * 2 + 0] = row_lo;
-    bounds[((long long)b * 8 + tid) * 2 + 1] = row_hi;
-  }
-}
-
-// One workgroup = `ipw` consecutive items of its XCD's share of one image ((box, output row) each: cw pixels x C channels,
-// one contiguous run of the output), ipw * cw <= 256: the items' pixel parameters are computed together by the first
-// ipw * cw lanes (item -> box -> coordinates: two dependent loads, paid once per workgroup instead of once per 16 KB), then
-// the workgroup streams the ipw runs like the box kernel streams a crop.  A pixel's parameters carry the position of its
-// C floats in the output (PixParam::pad, in float4 units), since consecutive items belong to different boxes.
-// Slot sequence of an XCD: pf warm-up workgroups for each of the first `lead` images, then per image b: pf warm-up
-// workgroups for image b + lead followed by the wpg = ceil(per / ipw) workgroups of the XCD's `per` items of image b.
-template <int WPE, int UNROLL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
-void crop_resize_rowband_kernel(const float *__restrict__ image, int B, int H, int W, int C, const float *__restrict__ boxes,
-                                const int *__restrict__ order, const int *__restrict__ bounds, int R, int ch, int cw,
-                                float extrap, float *__restrict__ out, int pf, int ipw, int lead) {
-  __shared__ PixParam pp[256];
-  const int tid = threadIdx.x;
-  const int g = blockIdx.x & 7;
-  int s = blockIdx.x >> 3;
-  const int n = R * ch;
-  const int per = (n + 7) >> 3;
-  const int wpg = (per + ipw - 1) / ipw;
-  int b, idx, bi;
-  if (s < pf * lead) {  // warm-up of the first `lead` images, up front
-    bi = s / pf;
-    idx = -1;
-    s -= bi * pf;  // piece
-    b = 0;
-  } else {
-    s -= pf * lead;
-    b = s / (pf + wpg);
-    s -= b * (pf + wpg);
-    idx = s - pf;  // < 0: warm-up piece s of image b + lead
-    bi = b + lead;
-  }
-  if (b >= B) return;
-  if (idx < 0) {
-    const int piece = s;
-    if (bi >= B) return;
-    const int row_lo = bounds[((long long)bi * 8 + g) * 2 + 0], row_hi = bounds[((long long)bi * 8 + g) * 2 + 1];
-    if (row_lo > row_hi) return;
-    const long long row_bytes = (long long)W * C * 4;
-    const char *src = reinterpret_cast<const char *>(image) + ((long long)bi * H + row_lo) * row_bytes;
-    const long long bytes = (long long)(row_hi - row_lo + 1) * row_bytes;
-    f32x4 acc = (f32x4)(0.0f);
-#pragma unroll 8
-    for (long long o = ((long long)piece * 256 + tid) * 16; o + 16 <= bytes; o += (long long)pf * 256 * 16) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(src + o);
-      acc.x += v.x;  // (any use keeps the load; nothing is stored)
-    }
-    asm volatile("" ::"v"(acc));
-    return;
-  }
-  // ranks [rank0, rank1) of the image's top order
-  const int rank0 = g * per + idx * ipw;
-  int rank1 = rank0 + ipw;
-  const int share_end = ((g + 1) * per < n) ? (g + 1) * per : n;
-  if (rank1 > share_end) rank1 = share_end;
-  if (rank0 >= rank1) return;
-  const int np = (rank1 - rank0) * cw;  // output pixels of this workgroup (<= 256)
-  const int CV = C >> 2;
-  if (tid < np) {
-    const int k = tid / cw, x = tid - k * cw;
-    const int item = order[(long long)b * n + rank0 + k];
-    const int r = item / ch, y = item - r * ch;
+    const int pos = atomicAdd(&bins[top], 1);  // (any order inside one source row: it only decides which lanes write the item)
+    const int r = i / ch, y = i - r * ch;
     const long long box = (long long)b * R + r;
     const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + box * 4);
-    PixParam prm = pix_param(y * cw + x, H, W, (unsigned)C * 4u, ch, cw, bx.x, bx.y, bx.z, bx.w, true);
-    prm.pad = (int)(((box * ch + y) * cw + x) * CV);  // < 2^31: host-checked
-    pp[tid] = prm;
-  }
-  __syncthreads();
-  const char *__restrict__ base = reinterpret_cast<const char *>(image + (long long)b * H * W * C);
-  f32x4 *__restrict__ out4 = reinterpret_cast<f32x4 *>(out);
-  const int total = np * CV;
-  int p = tid / CV;
-  int c = tid - p * CV;
-  const int dp = 256 / CV, dc = 256 - dp * CV;
-  for (int e0 = tid; e0 < total; e0 += 256 * UNROLL) {
-    f32x4 v[UNROLL];
-    unsigned at[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const bool in = e0 + u * 256 < total;
-      const PixParam prm = pp[in ? p : 0];
-      v[u] = bilerp<f32x4>(base, prm, (unsigned)(in ? c : 0) * 16u, extrap);
-      at[u] = (unsigned)prm.pad + (unsigned)c;
-      c += dc;
-      p += dp;
-      if (c >= CV) {
-        c -= CV;
-        ++p;
+    StageRec *out_rec = rec + ((long long)b * n + pos) * cw;
+    for (int x = 0; x < cw; ++x) {
+      const PixParam prm = pix_param(y * cw + x, H, W, 1u, ch, cw, bx.x, bx.y, bx.z, bx.w, true);  // offsets in pixels
+      StageRec o;
+      o.dst = (int)(((box * ch + y) * cw + x) * CV);
+      o.lx = prm.lx;
+      o.ly = prm.ly;
+      o.bits = 0u;
+      if (prm.valid) {  // (then its top row is this item's top: the same expression)
+        const unsigned left = prm.off_tl - (unsigned)top * (unsigned)W, right = prm.off_tr - (unsigned)top * (unsigned)W;
+        o.bits = left | (right << 10) | ((prm.off_bl == prm.off_tl ? 1u : 0u) << 20) | (1u << 21);
       }
+      out_rec[x] = o;
     }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
-      if (e0 + u * 256 < total) __builtin_nontemporal_store(v[u], out4 + at[u]);
   }
 }
 
-// ---- LDS-staged feature rows ------------------------------------------------------------------------------------------
-// With feature maps this large the RoIs span many source pixels, no two output pixels of a crop share a tap, and the tap
-// gather -- four 16-byte loads per 16 bytes written, every one of them an L1 miss -- runs into the L2's bandwidth: at
-// config 5 the taps alone take as long as the stores alone (110 us each, 165-175 together).  But the 300 RoIs of an image
-// overlap: every source pixel is sampled about 240 times.  So the roles are turned round.  A workgroup owns a STRIP of
-// consecutive source rows of one image and one part of the channels and walks it top to bottom with two row buffers in LDS
-// (row r lives in buffer r & 1): for the pair (t, t + 1) it produces every (RoI, output row) item of the image whose top
-// row is t -- the items come sorted by top from crop_rows_order_kernel, their per-pixel parameters precomputed in that
-// order -- with the taps read from LDS, then loads row t + 2 over row t.  Every source row travels from memory to a CU
-// once per channel part (plus once more at a strip boundary): 0.3 bytes through the L2 per byte written instead of 4.
-// The strips of an image hold equal numbers of items (not rows), so every workgroup of the launch has the same work.
-// The channels are cut into Q parts so that two rows fit the LDS: an item's output is cw runs of C / Q floats.
-// Rows go from global memory straight into LDS (global_load_lds: no registers; the LDS destination of such a load is
-// wave-uniform base + lane * 16, which is rows[j] for j = the wave's first j + lane).
-// LDS: 2 * W * CQ float4 of rows | ic * cw PixParam (off_* are float4 indices into the row buffers here).
+// grid: B * (H + 1) * Q workgroups of NT threads: (image b, top row t, channel part q).
+// LDS: 2 * W * CQ float4 of rows | ic * cw PixParam (off_* are float4 indices into the staged rows here).
 template <int NT>
 __global__ __launch_bounds__(NT) void crop_resize_rowstage_kernel(const float *__restrict__ image, int B, int H, int W, int C,
                                                                   const StageRec *__restrict__ rec,
-                                                                  const int *__restrict__ rowstart,
-                                                                  const int *__restrict__ strips, int R, int ch, int cw,
-                                                                  float extrap, float *__restrict__ out, int Q, int NS, int ic) {
+                                                                  const int *__restrict__ rowstart, int R, int ch, int cw,
+                                                                  float extrap, float *__restrict__ out, int Q, int ic) {
   extern __shared__ __attribute__((aligned(16))) f32x4 rows[];
   const int tid = threadIdx.x;
-  // NS > 0: strip k of the image's NS item-balanced strips; NS == 0: one source-row pair per workgroup (k = its top row)
-  const int per_image = NS > 0 ? NS : H + 1;
   const int q = blockIdx.x % Q;
-  const int k = (blockIdx.x / Q) % per_image;
-  const int b = blockIdx.x / (Q * per_image);
+  const int t = (blockIdx.x / Q) % (H + 1);
+  const int b = blockIdx.x / (Q * (H + 1));
   if (b >= B) return;
   const int n = R * ch;
-  const int t_begin = NS > 0 ? strips[(long long)b * 16 + k] : k;            // rows [t_begin, t_end), t_end <= H + 1
-  const int t_end = NS > 0 ? strips[(long long)b * 16 + k + 1] : k + 1;
-  const int *rs = rowstart + (long long)b * (H + 2);
-  const bool stamped = (b == B / 2) && (k == per_image / 2) && (q == 0);  // (diagnostic builds: one mid-image workgroup's phases)
+  const int r0 = rowstart[(long long)b * (H + 2) + t], r1 = rowstart[(long long)b * (H + 2) + t + 1];
+  if (r0 >= r1) return;  // nobody samples this row pair
+  const bool stamped = (b == B / 2) && (t == H / 2) && (q == 0);  // (diagnostic builds: one mid-image workgroup's phases)
   (void)stamped;
+  FRCNN_STAMP_IF(stamped, 60);
   const int CV = C >> 2, CQ = CV / Q;
   const int rowlen = W * CQ;  // float4 of one staged row
   PixParam *pp = reinterpret_cast<PixParam *>(rows + 2 * rowlen);
-  f32x4 *__restrict__ out4 = reinterpret_cast<f32x4 *>(out);
-  const int dp = NT / CQ, dcc = NT - dp * CQ;
-  const int lcol = tid / CQ, lc = tid - lcol * CQ;      // this thread's first (column, channel) of a row load
-  const int dcol = NT / CQ, dlc = NT - dcol * CQ;
-  // Barriers order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for vmcnt(0), i.e.
-  // for the acknowledgement of every output store issued so far, once per chunk.  For the same reason a chunk's records are
-  // requested before the previous chunk's stores are issued (vector-memory operations retire in order).
-  auto lds_barrier = []() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  auto load_row = [&](int r) {  // row r of this image, channel part q -> buffer r & 1
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(image + ((long long)b * H + r) * W * C) + q * CQ;
-    f32x4 *dst = rows + (r & 1) * rowlen;
-    int col = lcol, c = lc;
+  const StageRec *recs = rec + ((long long)b * n + r0) * cw;  // this row pair's pixels, contiguous
+  const int npix = (r1 - r0) * cw;
+  // the first chunk's records are requested BEFORE the rows, so that all of the workgroup's loads are one round trip
+  StageRec next = {};
+  {
+    const int np0 = (npix < ic * cw) ? npix : ic * cw;
+    if (tid < np0) next = recs[tid];
+  }
+  if (t < H) {  // (t == H: the rows without taps)
+    const int tb = (t + 1 < H) ? t + 1 : t;
+    const f32x4 *src_t = reinterpret_cast<const f32x4 *>(image + ((long long)b * H + t) * W * C) + q * CQ;
+    const f32x4 *src_b = reinterpret_cast<const f32x4 *>(image + ((long long)b * H + tb) * W * C) + q * CQ;
+    int col = tid / CQ, c = tid - col * CQ;
+    const int dcol = NT / CQ, dc = NT - dcol * CQ;
     for (int j = tid; j < rowlen; j += NT) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((long long)col * CV + c)),
-                                       (__attribute__((address_space(3))) void *)(dst + (j - (tid & 63))), 16, 0, 0);
-      c += dlc;
+      const int j0 = j - (tid & 63);
+      const long long gi = (long long)col * CV + c;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_t + gi),
+                                       (__attribute__((address_space(3))) void *)(rows + j0), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_b + gi),
+                                       (__attribute__((address_space(3))) void *)(rows + rowlen + j0), 16, 0, 0);
+      c += dc;
       col += dcol;
       if (c >= CQ) {
         c -= CQ;
         ++col;
       }
     }
-  };
-  int held0 = -1, held1 = -1;  // the rows in the two buffers (workgroup-uniform)
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0 = rs[t], r1 = rs[t + 1];
-    if (r0 >= r1) continue;  // nobody samples this row pair
-    FRCNN_STAMP_IF(stamped, 60);
-    const StageRec *recs = rec + ((long long)b * n + r0) * cw;  // this row pair's pixels, contiguous
-    const int npix = (r1 - r0) * cw;
-    // the first chunk's records are requested BEFORE the rows, so that all loads of this step are one round trip
-    StageRec next = {};
-    {
-      const int np0 = (npix < ic * cw) ? npix : ic * cw;
-      if (tid < np0) next = recs[tid];
-    }
-    bool loaded = false;
-    if (t < H) {  // (t == H: the rows without taps)
-      const int need0 = (t & 1) ? t + 1 : t, need1 = (t & 1) ? t : t + 1;  // the rows buffers 0 / 1 must hold
-      if (need0 < H && held0 != need0) {
-        load_row(need0);
-        held0 = need0;
-        loaded = true;
-      }
-      if (need1 < H && held1 != need1) {
-        load_row(need1);
-        held1 = need1;
-        loaded = true;
-      }
-    }
-    const unsigned topbase = (unsigned)((t & 1) * rowlen), botbase = (unsigned)(((t + 1) & 1) * rowlen);
-    for (int p0 = 0; p0 < npix; p0 += ic * cw) {
-      const int np = (npix - p0 < ic * cw) ? (npix - p0) : ic * cw;
-      if (p0 > 0) lds_barrier();  // the previous chunk's parameters are no longer read
-      if (tid < np) {
-        const StageRec rc = next;
-        PixParam prm;
-        const unsigned left = (rc.bits & 1023u) * (unsigned)CQ, right = ((rc.bits >> 10) & 1023u) * (unsigned)CQ;
-        const unsigned bb = ((rc.bits >> 20) & 1u) ? topbase : botbase;  // bot == top when in_y is integral
-        prm.off_tl = topbase + left;
-        prm.off_tr = topbase + right;
-        prm.off_bl = bb + left;
-        prm.off_br = bb + right;
-        prm.lx = rc.lx;
-        prm.ly = rc.ly;
-        prm.valid = (int)((rc.bits >> 21) & 1u);
-        prm.pad = rc.dst + q * CQ;
-        pp[tid] = prm;
-      }
-      if (p0 == 0 && loaded) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed in LDS
-      lds_barrier();
-      FRCNN_STAMP_IF(stamped, 62);
-      {
-        const int pn = p0 + ic * cw + tid;
-        if (pn < npix) next = recs[pn];
-      }
-      const int total = np * CQ;
-      int p = tid / CQ;
-      int c = tid - p * CQ;
-      for (int e0 = tid; e0 < total; e0 += NT * 4) {
-        f32x4 v[4];
-        unsigned at[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const bool in = e0 + u * NT < total;
-          const PixParam prm = pp[in ? p : 0];
-          const unsigned cc = in ? (unsigned)c : 0u;
-          // the three lerps of bilerp(), one rounding per operation, taps from LDS
-          const f32x4 tl = rows[prm.off_tl + cc], tr = rows[prm.off_tr + cc], bl = rows[prm.off_bl + cc], br = rows[prm.off_br + cc];
-          f32x4 tt = vsub(tr, tl);
-          tt = tt * prm.lx;
-          const f32x4 tp = tl + tt;
-          tt = vsub(br, bl);
-          tt = tt * prm.lx;
-          const f32x4 bt = bl + tt;
-          tt = vsub(bt, tp);
-          tt = tt * prm.ly;
-          f32x4 val = tp + tt;
-          if (!prm.valid) val = (f32x4)(extrap);
-          v[u] = val;
-          at[u] = (unsigned)prm.pad + cc;
-          c += dcc;
-          p += dp;
-          if (c >= CQ) {
-            c -= CQ;
-            ++p;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (e0 + u * NT < total) __builtin_nontemporal_store(v[u], out4 + at[u]);
-      }
-      FRCNN_STAMP_IF(stamped, 63);
-    }
-    lds_barrier();  // every wave is done with this pair's rows and parameters before the next step overwrites them
   }
-}
-
-// ---- the same, streamed: a strip per workgroup, the loads on their own waves -------------------------------------------------
-// crop_resize_rowstage_kernel stages a row pair, produces its items and ends: while its rows travel (8-9 us for 145 KB: the
-// CU's outstanding-miss budget against the fabric's latency) the CU stores nothing, and on gfx9 a wave that has issued
-// stores cannot wait for a later load without waiting for the stores' acknowledgements too (one in-order vmcnt).  Here a
-// workgroup walks one of the image's item-balanced STRIPS of rows top to bottom with FOUR row buffers (row r in buffer
-// r % 4) and two record buffers, and the waves are specialised:
-//   waves 15 / 14 load the even / odd rows (global_load_lds; row t + 3 is requested when the pair (t, t + 1) starts and
-//                  awaited when the pair (t + 1, t + 2) ends: two pairs of slack, and a loader never has two rows in flight,
-//                  so its wait is a plain vmcnt(0)),
-//   wave 13        loads records (global_load_lds; the next step's chunk of per-pixel records),
-//   waves 0-12     compute (taps and records from LDS, nontemporal stores; they never wait on vmcnt).
-// One s_barrier per step (a chunk of <= ic items of one row pair); every wave runs the same step sequence.  Every source row
-// travels to the CU once per channel part (three more at a strip boundary).
-// LDS: 4 * W * CQ float4 of rows | 2 * ic * cw StageRec | H + 2 ints (the image's rowstart).
-__global__ __launch_bounds__(1024) void crop_resize_rowstream_kernel(const float *__restrict__ image, int B, int H, int W, int C,
-                                                                     const StageRec *__restrict__ rec,
-                                                                     const int *__restrict__ rowstart,
-                                                                     const int *__restrict__ strips, int R, int ch, int cw,
-                                                                     float extrap, float *__restrict__ out, int Q, int NS, int ic) {
-  extern __shared__ __attribute__((aligned(16))) f32x4 rows[];
-  constexpr int kComputeWaves = 13, NTC = kComputeWaves * 64;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q = blockIdx.x % Q;
-  const int k = (blockIdx.x / Q) % NS;
-  const int b = blockIdx.x / (Q * NS);
-  if (b >= B) return;
-  const int n = R * ch;
-  const int CV = C >> 2, CQ = CV / Q;
-  const int rowlen = W * CQ;
-  const int chunk = ic * cw;  // pixels per step
-  StageRec *recbuf = reinterpret_cast<StageRec *>(rows + 4 * rowlen);  // [2][chunk]
-  int *rs = reinterpret_cast<int *>(recbuf + 2 * chunk);               // [H + 2]
-  const int t_begin = strips[(long long)b * 16 + k], t_end = strips[(long long)b * 16 + k + 1];  // rows [t_begin, t_end), t_end <= H + 1
-  if (t_begin >= t_end) return;
-  const StageRec *recs = rec + (long long)b * n * cw;  // the image's records, in rank order
   f32x4 *__restrict__ out4 = reinterpret_cast<f32x4 *>(out);
-  const int row_wave = 15 - 0;  // even rows; odd rows: wave 14
-
-  auto load_row = [&](int r) {  // row r of this image, channel part q -> buffer r % 4 (64 lanes, 16 bytes each per trip)
-    const f32x4 *src = reinterpret_cast<const f32x4 *>(image + ((long long)b * H + r) * W * C) + q * CQ;
-    f32x4 *dst = rows + (r & 3) * rowlen;
-    for (int j0 = 0; j0 < rowlen; j0 += 64) {
-      const int j = j0 + lane;
-      if (j < rowlen) {
-        const int col = j / CQ, c = j - col * CQ;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + ((long long)col * CV + c)),
-                                         (__attribute__((address_space(3))) void *)(dst + j0), 16, 0, 0);
-      }
-    }
-  };
-  auto is_loader_of = [&](int r) { return wave == row_wave - (r & 1); };
-  auto load_recs = [&](int first_pixel, int count, int buf) {  // wave 13: `count` records from first_pixel -> recbuf[buf]
-    StageRec *dst = recbuf + buf * chunk;
-    for (int j0 = 0; j0 < count; j0 += 64) {
-      if (j0 + lane < count)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(recs + first_pixel + j0 + lane),
-                                         (__attribute__((address_space(3))) void *)(dst + j0), 16, 0, 0);
-    }
-  };
-  auto step_barrier = [&]() {
+  const int dp = NT / CQ, dcc = NT - dp * CQ;
+  // Barriers inside this loop order LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for
+  // vmcnt(0), i.e. for the acknowledgement of every output store issued so far.  For the same reason the next chunk's
+  // records are requested before this chunk's stores are issued (vector-memory operations retire in order).
+  auto lds_barrier = []() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-
-  // prologue: the image's rowstart (every wave needs it to follow the step sequence), the first rows, the first chunk
-  for (int i = tid; i < H + 2; i += 1024) rs[i] = rowstart[(long long)b * (H + 2) + i];
-  if (wave >= 14) {
-    for (int r = t_begin; r < t_begin + 3; ++r)  // rows t, t + 1 of the first pair and the bot row of the second
-      if (r < H && (r == t_begin || r <= t_end) && is_loader_of(r)) load_row(r);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __syncthreads();  // rs (nothing has been stored yet: the full barrier costs nothing here)
-  if (wave == 13) {
-    const int r0 = rs[t_begin], r1 = rs[t_begin + 1];
-    const int np = ((r1 - r0) * cw < chunk) ? (r1 - r0) * cw : chunk;
-    load_recs(r0 * cw, np, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  step_barrier();
-
-  int step = 0;
-  for (int t = t_begin; t < t_end; ++t) {
-    const int r0 = rs[t], r1 = rs[t + 1];
-    const int npix = (r1 - r0) * cw;
-    const int nsteps = npix > 0 ? (npix + chunk - 1) / chunk : 1;  // a row nobody samples is one empty step
-    const unsigned topbase = (unsigned)((t & 3) * rowlen), botbase = (unsigned)(((t + 1) & 3) * rowlen);
-    for (int sidx = 0; sidx < nsteps; ++sidx, ++step) {
-      const int p0 = sidx * chunk;
-      const int np = (npix - p0 < chunk) ? (npix - p0) : chunk;  // (<= 0 for the empty step)
-      const bool last = sidx + 1 == nsteps;
-      FRCNN_STAMP_IF((b == B / 2) && (k == NS / 2) && (q == 0), 70 + (np > 0 ? (r1 - r0 > 99 ? 9 : (r1 - r0) / 11) : 0));
-      if (wave >= 14) {
-        // row t + 3 (the bot row of the pair after next) into the buffer of row t - 1, which nobody reads any more
-        if (sidx == 0 && t + 3 < H && t + 2 < t_end && is_loader_of(t + 3)) load_row(t + 3);
-        // row t + 2, requested a pair ago by this wave, must be there when the next pair starts
-        if (last && is_loader_of(t + 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else if (wave == 13) {
-        // the next step's records (this pair's next chunk, or the next pair's first) into the other buffer
-        int nf = -1, nc = 0;
-        if (!last) {
-          nf = r0 * cw + p0 + chunk;
-          nc = (npix - p0 - chunk < chunk) ? (npix - p0 - chunk) : chunk;
-        } else if (t + 1 < t_end) {
-          const int q0 = rs[t + 1], q1 = rs[t + 2];
-          nf = q0 * cw;
-          nc = ((q1 - q0) * cw < chunk) ? (q1 - q0) * cw : chunk;
-        }
-        if (nc > 0) load_recs(nf, nc, (step + 1) & 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else if (np > 0) {
-        const StageRec *rb = recbuf + (step & 1) * chunk;
-        const int total = np * CQ;
-        int p = tid / CQ;
-        int c = tid - p * CQ;
-        const int dp = NTC / CQ, dcc = NTC - dp * CQ;
-        for (int e0 = tid; e0 < total; e0 += NTC * 4) {
-          f32x4 v[4];
-          unsigned at[4];
+  for (int p0 = 0; p0 < npix; p0 += ic * cw) {
+    const int np = (npix - p0 < ic * cw) ? (npix - p0) : ic * cw;
+    if (p0 > 0) lds_barrier();  // the previous chunk's parameters are no longer read
+    FRCNN_STAMP_IF(stamped, 61);
+    if (tid < np) {
+      const StageRec rc = next;
+      PixParam prm;
+      const unsigned left = (rc.bits & 1023u) * (unsigned)CQ, right = ((rc.bits >> 10) & 1023u) * (unsigned)CQ;
+      const unsigned brow = ((rc.bits >> 20) & 1u) ? 0u : (unsigned)rowlen;  // bot == top when in_y is integral
+      prm.off_tl = left;
+      prm.off_tr = right;
+      prm.off_bl = brow + left;
+      prm.off_br = brow + right;
+      prm.lx = rc.lx;
+      prm.ly = rc.ly;
+      prm.valid = (int)((rc.bits >> 21) & 1u);
+      prm.pad = rc.dst + q * CQ;
+      pp[tid] = prm;
+    }
+    if (p0 == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged rows have landed in LDS
+    lds_barrier();
+    FRCNN_STAMP_IF(stamped, 62);
+    {
+      const int pn = p0 + ic * cw + tid;
+      if (pn < npix) next = recs[pn];
+    }
+    const int total = np * CQ;
+    int p = tid / CQ;
+    int c = tid - p * CQ;
+    for (int e0 = tid; e0 < total; e0 += NT * 4) {
+      f32x4 v[4];
+      unsigned at[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool in = e0 + u * NTC < total;
-            const StageRec rc = rb[in ? p : 0];
-            const unsigned cc = in ? (unsigned)c : 0u;
-            const unsigned left = (rc.bits & 1023u) * (unsigned)CQ, right = ((rc.bits >> 10) & 1023u) * (unsigned)CQ;
-            const unsigned bb = ((rc.bits >> 20) & 1u) ? topbase : botbase;  // bot == top when in_y is integral
-            // the three lerps of bilerp(), one rounding per operation, taps from LDS
-            const f32x4 tl = rows[topbase + left + cc], tr = rows[topbase + right + cc], bl = rows[bb + left + cc],
-                        br = rows[bb + right + cc];
-            f32x4 tt = vsub(tr, tl);
-            tt = tt * rc.lx;
-            const f32x4 tp = tl + tt;
-            tt = vsub(br, bl);
-            tt = tt * rc.lx;
-            const f32x4 bt = bl + tt;
-            tt = vsub(bt, tp);
-            tt = tt * rc.ly;
-            f32x4 val = tp + tt;
-            if (!((rc.bits >> 21) & 1u)) val = (f32x4)(extrap);
-            v[u] = val;
-            at[u] = (unsigned)(rc.dst + q * CQ) + cc;
-            c += dcc;
-            p += dp;
-            if (c >= CQ) {
-              c -= CQ;
-              ++p;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            if (e0 + u * NTC < total) __builtin_nontemporal_store(v[u], out4 + at[u]);
+      for (int u = 0; u < 4; ++u) {
+        const bool in = e0 + u * NT < total;
+        const PixParam prm = pp[in ? p : 0];
+        const unsigned cc = in ? (unsigned)c : 0u;
+        // the three lerps of bilerp(), one rounding per operation, taps from LDS
+        const f32x4 tl = rows[prm.off_tl + cc], tr = rows[prm.off_tr + cc], bl = rows[prm.off_bl + cc], br = rows[prm.off_br + cc];
+        f32x4 tt = vsub(tr, tl);
+        tt = tt * prm.lx;
+        const f32x4 tp = tl + tt;
+        tt = vsub(br, bl);
+        tt = tt * prm.lx;
+        const f32x4 bt = bl + tt;
+        tt = vsub(bt, tp);
+        tt = tt * prm.ly;
+        f32x4 val = tp + tt;
+        if (!prm.valid) val = (f32x4)(extrap);
+        v[u] = val;
+        at[u] = (unsigned)prm.pad + cc;
+        c += dcc;
+        p += dp;
+        if (c >= CQ) {
+          c -= CQ;
+          ++p;
         }
       }
-      FRCNN_STAMP_IF((b == B / 2) && (k == NS / 2) && (q == 0), 80);
-      step_barrier();
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + u * NT < total) __builtin_nontemporal_store(v[u], out4 + at[u]);
     }
+    FRCNN_STAMP_IF(stamped, 63);
   }
 }
 
@@ -1092,15 +762,14 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   return check_launch("crop_and_resize");
 }
 
-// order of the (box, output row) items (source-row ownership, crop heights up to kRowbandMaxCh) | per-image row bounds;
-// the RoI order of the sorted channel-slice sweep shares the front of the same area
-static const int kRowbandMaxCh = 16;
-static const int kStageMaxPixels = 64;  // crop_h * crop_w up to which the LDS-staged form keeps per-pixel records
+// frcnn_roi_pooling's workspace: the RoI order of the sorted channel-slice sweep (B*R ints) at the front; for the
+// LDS-staged form the per-image rowstart (H + 2 <= 1032 ints) and the per-pixel records (crop_h * crop_w <= kStageMaxPixels)
+static const int kStageMaxPixels = 64;
+static size_t stage_rowstart_offset(int B, int R) { return round_up((size_t)B * R * sizeof(int), 256); }
+static size_t stage_rec_offset(int B, int R) { return stage_rowstart_offset(B, R) + round_up((size_t)B * 1032 * sizeof(int), 256); }
 extern "C" size_t frcnn_roi_pooling_workspace_bytes(int B, int R) {
   if (B <= 0 || R <= 0) return 256;
-  return round_up((size_t)B * R * kRowbandMaxCh * sizeof(int), 256) + round_up((size_t)B * 16 * sizeof(int), 256) +
-         round_up((size_t)B * 1032 * sizeof(int), 256) +                                   // order | bounds | rowstart (H <= 1023)
-         round_up((size_t)B * R * kStageMaxPixels * sizeof(StageRec), 256) + 256;          // | per-pixel records
+  return stage_rec_offset(B, R) + round_up((size_t)B * R * kStageMaxPixels * sizeof(StageRec), 256) + 256;
 }
 
 extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
@@ -1122,40 +791,28 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
   // A launch of at most 1024 boxes (batch 1-3 at 300 RoIs) does not fill the chip with one workgroup per box -- four fit on a
   // CU -- and is bound by the time ONE workgroup takes for its 113 KB crop: the same split, four workgroups per box, no
   // warm-up, runs the crop of config 1 in 12.6 instead of 16.6 us (B = 2: -10 %, B = 3: -12 %, B = 4: -3 %, B = 8: none).
-  // Source-row ownership (crop_resize_rowband_kernel): the default beyond 4 MiB per image when the caller brings the
-  // workspace; FRCNN_CROP_ROWBAND = 0 | 1 forces the choice for any size (1 still needs the workspace and the shape limits).
+  // LDS-staged feature rows (crop_resize_rowstage_kernel): the default beyond 4 MiB per image when the caller brings the
+  // workspace; FRCNN_CROP_STAGE = 0 | 1 forces the choice for any size (1 still needs the workspace and the shape limits;
+  // with it FRCNN_CROP_SPLIT = Q sets a minimum number of channel parts: diagnostic).
   {
-    const int rb = knob(kKnobCropRowband, -1);
+    const int rb = knob(kKnobCropStage, -1);
     const bool want = rb >= 0 ? rb != 0 : (image_bytes > 4ll * 1024 * 1024 && !knob_set(kKnobCropSplit) && !knob_set(kKnobCropSlice));
     const long long nb = (long long)R * crop_h;
+    const int NT = 1024;
+    int ic = 64;  // items per chunk of parameters
+    if (crop_w > 0 && ic * crop_w > NT) ic = NT / crop_w;
+    const int CV = C / 4;
+    int Q = 0;
+    size_t stage_lds = 0;
     const bool fits = H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
-                      aligned_to(out, 16) && aligned_to(rois, 16) && image_bytes < (1ll << 32) && H <= 1023 &&
-                      crop_h <= kRowbandMaxCh && nb <= 24000 && (long long)crop_h * crop_w < (1ll << 24) &&
-                      crop_w <= 256 && (long long)B * R * crop_h * crop_w * (C / 4) < (1ll << 31) && workspace &&
-                      aligned_to(workspace, 256) &&
+                      aligned_to(out, 16) && aligned_to(rois, 16) && image_bytes < (1ll << 32) && H <= 1023 && W <= 1023 &&
+                      nb <= 65535 && crop_h * crop_w <= kStageMaxPixels && ic > 0 &&
+                      (long long)B * R * crop_h * crop_w * CV < (1ll << 31) && workspace && aligned_to(workspace, 256) &&
                       workspace_bytes >= frcnn_roi_pooling_workspace_bytes(B, R);
     if (want && fits) {
-      int *order = reinterpret_cast<int *>(workspace);
-      int *bounds = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + round_up((size_t)B * R * kRowbandMaxCh * sizeof(int), 256));
-      const size_t lds = (size_t)(1024 + 8 + 16) * 4 + (size_t)(((nb + 1) & ~1ll) * 2) * 2;
-      auto okern = crop_rows_order_kernel;
-      if (lds > 48 * 1024) {
-        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(okern), lds, "roi_pooling: hipFuncSetAttribute");
-        if (rc) return rc;
-      }
-      int *rowstart = bounds + round_up((size_t)B * 16 * sizeof(int), 256) / sizeof(int);
-      StageRec *rec = reinterpret_cast<StageRec *>(rowstart + round_up((size_t)B * 1032 * sizeof(int), 256) / sizeof(int));
-      // LDS-staged rows (crop_resize_rowstage_kernel): Q = the fewest channel parts (1 / 2 / 4 / 8) with which the two rows and
-      // the parameters fit the CU's LDS.  FRCNN_CROP_ROWBAND = 2 forces it, 1 forces the tap-gather form below.
-      const int NT = 1024;
-      int ic = 64;
-      if (ic * crop_w > NT) ic = NT / crop_w;
-      const int CV = C / 4;
-      int Q = 0;
-      size_t stage_lds = 0;
-      const int q_forced = rb >= 2 ? knob(kKnobCropSplit, 0) : 0;  // (diagnostic: FRCNN_CROP_SPLIT = Q with FRCNN_CROP_ROWBAND = 2)
-      for (int cand = 1; cand <= 8 && ic > 0 && crop_h * crop_w <= kStageMaxPixels && W <= 1023; cand *= 2) {
-        if (CV % cand || cand < q_forced) continue;
+      const int q_min = rb > 0 ? knob(kKnobCropSplit, 0) : 0;
+      for (int cand = 1; cand <= 8; cand *= 2) {  // the fewest channel parts with which two rows and the parameters fit the LDS
+        if (CV % cand || cand < q_min) continue;
         const size_t need = (size_t)2 * W * (CV / cand) * 16 + (size_t)ic * crop_w * sizeof(PixParam);
         if (need <= 160 * 1024) {
           Q = cand;
@@ -1163,71 +820,30 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
           break;
         }
       }
-      // the streamed form: four row buffers, two record buffers and the image's rowstart
-      int Qs = 0;
-      size_t stream_lds = 0;
-      for (int cand = 1; cand <= 8 && ic > 0 && Q > 0; cand *= 2) {
-        if (CV % cand || cand < q_forced) continue;
-        const size_t need = (size_t)4 * W * (CV / cand) * 16 + (size_t)2 * ic * crop_w * sizeof(StageRec) + (size_t)(H + 2) * 4 + 16;
-        if (need <= 160 * 1024) {
-          Qs = cand;
-          stream_lds = need;
-          break;
-        }
+    }
+    if (Q > 0) {
+      int *rowstart = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + stage_rowstart_offset(B, R));
+      StageRec *rec = reinterpret_cast<StageRec *>(reinterpret_cast<char *>(workspace) + stage_rec_offset(B, R));
+      const size_t lds = (size_t)(1024 + 8 + 16) * 4 + (size_t)((nb + 1) & ~1ll) * 2;
+      auto okern = crop_rows_order_kernel;
+      if (lds > 48 * 1024) {
+        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(okern), lds, "roi_pooling: hipFuncSetAttribute");
+        if (rc) return rc;
       }
-      const bool stage = Q > 0 && (rb >= 0 ? (rb == 2 || (rb == 3 && Qs > 0)) : true);
-      // strips per image: FRCNN_CROP_PREFETCH = n (1..15) makes a workgroup walk one of n item-balanced strips of rows with a
-      // sliding two-row window instead (diagnostic)
-      int NS = 0;  // one row pair per workgroup by default (measured below)
-      if (rb == 3 && Qs > 0) NS = (256 + B * Qs - 1) / (B * Qs);  // the streamed form: one strip per CU
-      if (knob(kKnobCropPrefetch, -1) > 0) NS = knob(kKnobCropPrefetch, -1);
-      if (NS > 15) NS = 15;
-      if (rb == 3 && NS < 1) NS = 1;
-      hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, rois, R, H, crop_h, order, bounds, rowstart,
-                         stage ? rec : (StageRec *)nullptr, W, crop_w, CV, NS);
+      hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, rois, R, H, W, crop_h, crop_w, CV, rowstart,
+                         rec);
       int rc = check_launch("roi_pooling (row order)");
       if (rc) return rc;
-      if (stage && rb == 3) {  // the streamed form (crop_resize_rowstream_kernel)
-        auto skern = crop_resize_rowstream_kernel;
-        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), stream_lds, "roi_pooling: hipFuncSetAttribute");
+      auto skern = crop_resize_rowstage_kernel<1024>;
+      if (stage_lds > 48 * 1024) {
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), stage_lds, "roi_pooling: hipFuncSetAttribute");
         if (rc) return rc;
-        hipLaunchKernelGGL(skern, dim3((unsigned)(B * Qs * NS)), dim3(1024), stream_lds, (hipStream_t)stream, feature_map, B, H, W, C,
-                           rec, rowstart, bounds, R, crop_h, crop_w, 0.0f, out, Qs, NS, ic);
-        return check_launch("roi_pooling (streamed rows)");
       }
-      if (stage) {
-        auto skern = crop_resize_rowstage_kernel<1024>;
-        if (stage_lds > 48 * 1024) {
-          rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), stage_lds, "roi_pooling: hipFuncSetAttribute");
-          if (rc) return rc;
-        }
-        const long long wgs = (long long)B * Q * (NS > 0 ? NS : H + 1);
-        FRCNN_REQUIRE(wgs < (1ll << 31), "roi_pooling: too many workgroups");
-        hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(NT), stage_lds, (hipStream_t)stream, feature_map, B, H, W, C,
-                           rec, rowstart, bounds, R, crop_h, crop_w, 0.0f, out, Q, NS, ic);
-        return check_launch("roi_pooling (staged rows)");
-      }
-      // warm-up workgroups per (XCD, image): FRCNN_CROP_PREFETCH as for the other schedules (0 = none)
-      int pf = knob(kKnobCropPrefetch, B > 1 ? 16 : 0), ipw_forced = 0, lead_forced = 0;
-      if (pf >= 10000) {  // diagnostic: lead in images * 1000000 + items per workgroup * 10000 + warm-up workgroups
-        lead_forced = pf / 1000000;
-        ipw_forced = (pf / 10000) % 100;
-        pf %= 10000;
-      }
-      if (pf > 256) pf = 256;
-      if (pf < 0) pf = 0;
-      // items per workgroup: a crop's worth (the box kernel's granularity), at most what 256 parameter lanes hold
-      int ipw = ipw_forced > 0 ? ipw_forced : crop_h;
-      if (ipw * crop_w > 256) ipw = 256 / crop_w;
-      const long long per = (nb + 7) / 8;
-      const long long wpg = (per + ipw - 1) / ipw;
-      int lead = lead_forced > 0 ? lead_forced : 1;
-      if (lead > B) lead = B;
-      const long long slots = (long long)pf * lead + (long long)B * (pf + wpg);
-      FRCNN_REQUIRE(slots * 8 < (1ll << 31), "roi_pooling: too many workgroups");
-      hipLaunchKernelGGL((crop_resize_rowband_kernel<FRCNN_CROP_WAVES_PER_EU, 4>), dim3((unsigned)(slots * 8)), dim3(256), 0,
-                         (hipStream_t)stream, feature_map, B, H, W, C, rois, order, bounds, R, crop_h, crop_w, 0.0f, out, pf, ipw, lead);
-      return check_launch("roi_pooling (row bands)");
+      const long long wgs = (long long)B * Q * (H + 1);
+      FRCNN_REQUIRE(wgs < (1ll << 31), "roi_pooling: too many workgroups");
+      hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(NT), stage_lds, (hipStream_t)stream, feature_map, B, H, W, C, rec, rowstart,
+                         R, crop_h, crop_w, 0.0f, out, Q, ic);
+      return check_launch("roi_pooling (staged rows)");
     }
   }
   int S = knob(kKnobCropSplit, -1);
