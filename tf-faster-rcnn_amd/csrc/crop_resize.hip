@@ -336,10 +336,10 @@ struct __attribute__((aligned(16))) StageRec {
 };
 
 // One workgroup of 1024 threads per image.  rowstart[b*(H + 2) + t] = rank of the first item of image b whose top row is t
-// (t = H: the rows whose in_y is out of range -- no taps, sorted last; t = H + 1: n = R * ch); rec[(b*n + rank)*cw + x] = the
-// parameters of output pixel x of the item at that rank.  LDS: 1024 + 8 bins | 16 wave sums | n tops (uint16).
-__global__ __launch_bounds__(1024) void crop_rows_order_kernel(const float *__restrict__ boxes, int R, int H, int W, int ch, int cw,
-                                                               int CV, int *__restrict__ rowstart, StageRec *__restrict__ rec) {
+// (t = H: the rows whose in_y is out of range -- no taps, sorted last; t = H + 1: n = R * ch); rank_top[b*n + i] = rank of item
+// i = r * ch + y in that order, with its top row in the upper 16 bits.  LDS: 1024 + 8 bins | 16 wave sums | n tops (uint16).
+__global__ __launch_bounds__(1024) void crop_rows_order_kernel(const float *__restrict__ boxes, int R, int H, int ch,
+                                                               int *__restrict__ rowstart, unsigned *__restrict__ rank_top) {
   extern __shared__ __attribute__((aligned(16))) int sm[];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = R * ch;
@@ -388,24 +388,37 @@ __global__ __launch_bounds__(1024) void crop_rows_order_kernel(const float *__re
   for (int i = tid; i < n; i += 1024) {
     const int top = tops[i];
     const int pos = atomicAdd(&bins[top], 1);  // (any order inside one source row: it only decides which lanes write the item)
-    const int r = i / ch, y = i - r * ch;
-    const long long box = (long long)b * R + r;
-    const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + box * 4);
-    StageRec *out_rec = rec + ((long long)b * n + pos) * cw;
-    for (int x = 0; x < cw; ++x) {
-      const PixParam prm = pix_param(y * cw + x, H, W, 1u, ch, cw, bx.x, bx.y, bx.z, bx.w, true);  // offsets in pixels
-      StageRec o;
-      o.dst = (int)(((box * ch + y) * cw + x) * CV);
-      o.lx = prm.lx;
-      o.ly = prm.ly;
-      o.bits = 0u;
-      if (prm.valid) {  // (then its top row is this item's top: the same expression)
-        const unsigned left = prm.off_tl - (unsigned)top * (unsigned)W, right = prm.off_tr - (unsigned)top * (unsigned)W;
-        o.bits = left | (right << 10) | ((prm.off_bl == prm.off_tl ? 1u : 0u) << 20) | (1u << 21);
-      }
-      out_rec[x] = o;
-    }
+    rank_top[(long long)b * n + i] = (unsigned)pos | ((unsigned)top << 16);
   }
+}
+
+// rec[(b*n + rank)*cw + x] = the sampling parameters of output pixel x of the item at that rank: one thread per output pixel
+// of the launch (the order kernel is one workgroup per image; these B*R*ch*cw coordinate computations would triple its time).
+__global__ __launch_bounds__(256) void crop_rows_records_kernel(const float *__restrict__ boxes, int B, int R, int H, int W, int ch,
+                                                                int cw, int CV, const unsigned *__restrict__ rank_top,
+                                                                StageRec *__restrict__ rec) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = R * ch;
+  if (e >= (long long)B * n * cw) return;
+  const long long item_g = e / cw;  // b*n + i
+  const int x = (int)(e - item_g * cw);
+  const int b = (int)(item_g / n), i = (int)(item_g - (long long)b * n);
+  const int r = i / ch, y = i - r * ch;
+  const unsigned rt = rank_top[item_g];
+  const int pos = (int)(rt & 0xFFFFu), top = (int)(rt >> 16);
+  const long long box = (long long)b * R + r;
+  const f32x4 bx = *reinterpret_cast<const f32x4 *>(boxes + box * 4);
+  const PixParam prm = pix_param(y * cw + x, H, W, 1u, ch, cw, bx.x, bx.y, bx.z, bx.w, true);  // offsets in pixels
+  StageRec o;
+  o.dst = (int)(((box * ch + y) * cw + x) * CV);
+  o.lx = prm.lx;
+  o.ly = prm.ly;
+  o.bits = 0u;
+  if (prm.valid) {  // (then its top row is the item's top: the same expression)
+    const unsigned left = prm.off_tl - (unsigned)top * (unsigned)W, right = prm.off_tr - (unsigned)top * (unsigned)W;
+    o.bits = left | (right << 10) | ((prm.off_bl == prm.off_tl ? 1u : 0u) << 20) | (1u << 21);
+  }
+  rec[((long long)b * n + pos) * cw + x] = o;
 }
 
 // grid: B * (H + 1) * Q workgroups of NT threads: (image b, top row t, channel part q).
@@ -763,10 +776,12 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
 }
 
 // frcnn_roi_pooling's workspace: the RoI order of the sorted channel-slice sweep (B*R ints) at the front; for the
-// LDS-staged form the per-image rowstart (H + 2 <= 1032 ints) and the per-pixel records (crop_h * crop_w <= kStageMaxPixels)
+// LDS-staged form the per-image rowstart (H + 2 <= 1032 ints), the items' ranks and the per-pixel records (crop_h * crop_w <=
+// kStageMaxPixels)
 static const int kStageMaxPixels = 64;
 static size_t stage_rowstart_offset(int B, int R) { return round_up((size_t)B * R * sizeof(int), 256); }
-static size_t stage_rec_offset(int B, int R) { return stage_rowstart_offset(B, R) + round_up((size_t)B * 1032 * sizeof(int), 256); }
+static size_t stage_rank_offset(int B, int R) { return stage_rowstart_offset(B, R) + round_up((size_t)B * 1032 * sizeof(int), 256); }
+static size_t stage_rec_offset(int B, int R) { return stage_rank_offset(B, R) + round_up((size_t)B * R * kStageMaxPixels * sizeof(int), 256); }
 extern "C" size_t frcnn_roi_pooling_workspace_bytes(int B, int R) {
   if (B <= 0 || R <= 0) return 256;
   return stage_rec_offset(B, R) + round_up((size_t)B * R * kStageMaxPixels * sizeof(StageRec), 256) + 256;
@@ -806,7 +821,7 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
     size_t stage_lds = 0;
     const bool fits = H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
                       aligned_to(out, 16) && aligned_to(rois, 16) && image_bytes < (1ll << 32) && H <= 1023 && W <= 1023 &&
-                      nb <= 65535 && crop_h * crop_w <= kStageMaxPixels && ic > 0 &&
+                      nb <= 65535 && crop_h * crop_w <= kStageMaxPixels && ic > 0 && (long long)B * nb * crop_w < (1ll << 31) &&
                       (long long)B * R * crop_h * crop_w * CV < (1ll << 31) && workspace && aligned_to(workspace, 256) &&
                       workspace_bytes >= frcnn_roi_pooling_workspace_bytes(B, R);
     if (want && fits) {
@@ -830,9 +845,14 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
         int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(okern), lds, "roi_pooling: hipFuncSetAttribute");
         if (rc) return rc;
       }
-      hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, rois, R, H, W, crop_h, crop_w, CV, rowstart,
-                         rec);
+      unsigned *rank_top = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + stage_rank_offset(B, R));
+      hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, rois, R, H, crop_h, rowstart, rank_top);
       int rc = check_launch("roi_pooling (row order)");
+      if (rc) return rc;
+      const long long npix_all = (long long)B * nb * crop_w;
+      hipLaunchKernelGGL(crop_rows_records_kernel, dim3((unsigned)((npix_all + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rois, B, R,
+                         H, W, crop_h, crop_w, CV, rank_top, rec);
+      rc = check_launch("roi_pooling (records)");
       if (rc) return rc;
       auto skern = crop_resize_rowstage_kernel<1024>;
       if (stage_lds > 48 * 1024) {

@@ -168,6 +168,7 @@ def case_decoder(name, B, R, L, iters):
 
 
 CASES = {
+    "crop_cfg1": lambda it: case_crop("crop_cfg1", 1, 32, 576, 300, 6000, it),  # one image: the small-launch four-slice schedule
     "crop_cfg2": lambda it: case_crop("crop_cfg2", 16, 32, 576, 300, 6000, it),
     "crop_cfg3": lambda it: case_crop("crop_cfg3", 16, 31, 512, 2000, 6000, it),  # one GPU's shard of B=32 over 2 GPUs
     "crop_cfg5": lambda it: case_crop("crop_cfg5", 16, 63, 576, 300, 12000, it),  # one GPU's shard of B=128 over 8
