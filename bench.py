@@ -218,8 +218,9 @@ class Workload:
             else:
                 self.roi_delta = pkg.faster_rcnn.RoIDelta(hp, name="roi_deltas")
             # (frcnn_roi_pooling's choice: feature maps beyond an XCD's L2, or a launch of at most 1024 boxes)
-            slice_kernel = cfg["G"] * cfg["G"] * cfg["C"] * 4 > 4 * 1024 * 1024 or B * cfg["R"] <= 1024
-            self.dominant = "crop_resize_slice_kernel" if slice_kernel else "crop_resize_kernel<4>"
+            staged = cfg["G"] * cfg["G"] * cfg["C"] * 4 > 4 * 1024 * 1024
+            self.dominant = ("crop_rows_order_kernel + crop_rows_records_kernel + crop_resize_rowstage_kernel<1024>" if staged else
+                             "crop_resize_slice_kernel" if B * cfg["R"] <= 1024 else "crop_resize_kernel<4>")
             self.dominant_bytes = crop_bytes_per_image(cfg) * B
             self.bound = "hbm"
         self.seed = seed

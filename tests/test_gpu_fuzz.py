@@ -186,7 +186,8 @@ def test_fuzz_roi_pooling_staged_rows(pkg, knobs):
     """frcnn_roi_pooling's schedule for feature maps beyond an XCD's L2 (the (RoI, output row) items of every image ordered by
     the source row they sample, a workgroup per source-row pair and channel part with the two rows staged in LDS by
     global_load_lds), forced on small shapes: out-of-range rows (no taps, sorted last), a single source row, rows nobody
-    samples, NaN boxes, several parameter chunks per row pair, every number of channel parts; the grouped entry point with a
+    samples, NaN boxes, several parameter chunks per row pair, every number of channel parts, every dealing of the row pairs
+    to the XCDs; the grouped entry point with a
     workspace takes the same route.  Bit-exact: every output lands in its own slot."""
     rng = np.random.default_rng(29)
     lib = pkg._lib.lib()
@@ -202,6 +203,11 @@ def test_fuzz_roi_pooling_staged_rows(pkg, knobs):
             knobs.setenv("FRCNN_CROP_SPLIT", q_min)
         else:
             knobs.delenv("FRCNN_CROP_SPLIT")
+        rg = [None, 0, 1, 2, 3, 4, 8, 64][case % 8]  # row pairs per XCD group (None: the library's choice for this H)
+        if rg is None:
+            knobs.delenv("FRCNN_CROP_PREFETCH")
+        else:
+            knobs.setenv("FRCNN_CROP_PREFETCH", rg)
         fm = rng.normal(0, 1, (B, H, W, C)).astype(np.float32)
         lo, hi = [(-0.2, 1.2), (0.0, 1.0), (-2.0, 3.0), (0.4, 0.6)][case % 4]
         rois = rng.uniform(lo, hi, (B, R, 4)).astype(np.float32)
@@ -214,7 +220,7 @@ def test_fuzz_roi_pooling_staged_rows(pkg, knobs):
         hp = synth.hyper_params(pooling_size=(ph, pw))
         want = oracle.roi_pooling(fm, rois, (ph, pw))
         got = pkg.faster_rcnn.RoIPooling(hp)([dev(fm), dev(rois)])
-        assert_bits(got, want, f"RoIPooling staged-rows case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw}) Q>={q_min}")
+        assert_bits(got, want, f"RoIPooling staged-rows case {case}: B={B} H={H} W={W} C={C} R={R} crop=({ph},{pw}) Q>={q_min} rg={rg}")
         if case % 4 == 0 and C % 4 == 0:  # the grouped entry point hands the RoIPooling layout to frcnn_roi_pooling when a knob is forced
             g = 1 + case % 3
             fms, rs = [dev(fm) for _ in range(g)], [dev(rois) for _ in range(g)]

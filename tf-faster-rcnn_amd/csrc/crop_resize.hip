@@ -421,18 +421,34 @@ __global__ __launch_bounds__(256) void crop_rows_records_kernel(const float *__r
   rec[((long long)b * n + pos) * cw + x] = o;
 }
 
-// grid: B * (H + 1) * Q workgroups of NT threads: (image b, top row t, channel part q).
+// grid: one workgroup of NT threads per (image b, top row t <= H, channel part q); see the index decode for the order.
 // LDS: 2 * W * CQ float4 of rows | ic * cw PixParam (off_* are float4 indices into the staged rows here).
 template <int NT>
 __global__ __launch_bounds__(NT) void crop_resize_rowstage_kernel(const float *__restrict__ image, int B, int H, int W, int C,
                                                                   const StageRec *__restrict__ rec,
                                                                   const int *__restrict__ rowstart, int R, int ch, int cw,
-                                                                  float extrap, float *__restrict__ out, int Q, int ic) {
+                                                                  float extrap, float *__restrict__ out, int Q, int ic, int rg,
+                                                                  int gpx) {
   extern __shared__ __attribute__((aligned(16))) f32x4 rows[];
   const int tid = threadIdx.x;
-  const int q = blockIdx.x % Q;
-  const int t = (blockIdx.x / Q) % (H + 1);
-  const int b = blockIdx.x / (Q * (H + 1));
+  int q, t, b;
+  if (rg > 0) {
+    // Workgroups are dealt to the 8 XCDs by blockIdx % 8.  Row t is loaded twice, as the top of pair t and as the bottom of
+    // pair t - 1: groups of rg consecutive pairs go to ONE XCD, back to back in its dispatch order, so that the second load
+    // of a row finds it in that XCD's L2 (group k of an image -> XCD k % 8, so an XCD gets groups from all over the image).
+    const int x = blockIdx.x & 7, s = blockIdx.x >> 3;
+    const int per_image = gpx * rg * Q;  // slots of one image on one XCD
+    b = s / per_image;
+    const int rem = s - b * per_image;
+    const int gl = rem / (rg * Q), in_g = rem - gl * (rg * Q);
+    t = (gl * 8 + x) * rg + in_g / Q;
+    q = in_g % Q;
+    if (t > H) return;
+  } else {
+    q = blockIdx.x % Q;
+    t = (blockIdx.x / Q) % (H + 1);
+    b = blockIdx.x / (Q * (H + 1));
+  }
   if (b >= B) return;
   const int n = R * ch;
   const int r0 = rowstart[(long long)b * (H + 2) + t], r1 = rowstart[(long long)b * (H + 2) + t + 1];
@@ -859,10 +875,22 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
         rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), stage_lds, "roi_pooling: hipFuncSetAttribute");
         if (rc) return rc;
       }
-      const long long wgs = (long long)B * Q * (H + 1);
+      // Row pairs per XCD group: the largest of 8 / 4 / 2 that deals the H + 1 pairs to the 8 XCDs within 7 % of evenly, else 0
+      // (pairs dealt round-robin, every row fetched twice).  Config 5 (H = 63), 16 images, cold inputs, FETCH_SIZE x 2 / kernel
+      // time under the profiler / crop time in the stage pipeline: 0: 298 MB, 145.3 us, 156.6 us; 4: 185 MB, 141.4, 154.9;
+      // 8: 166 MB (1.14 x the feature maps), 143.6, 155.4.  FRCNN_CROP_PREFETCH overrides (diagnostic).
+      int rg = 0;
+      for (int cand = 8; cand >= 2 && !rg; cand >>= 1) {
+        const int slots = (((H + 1 + cand - 1) / cand + 7) / 8) * 8 * cand;
+        if ((long long)slots * 100 <= (long long)(H + 1) * 107) rg = cand;
+      }
+      rg = knob(kKnobCropPrefetch, rg);
+      rg = rg < 0 ? 0 : (rg > 64 ? 64 : rg);
+      const int gpx = rg > 0 ? ((H + 1 + rg - 1) / rg + 7) / 8 : 0;  // groups of one image per XCD
+      const long long wgs = rg > 0 ? (long long)8 * B * gpx * rg * Q : (long long)B * Q * (H + 1);
       FRCNN_REQUIRE(wgs < (1ll << 31), "roi_pooling: too many workgroups");
       hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(NT), stage_lds, (hipStream_t)stream, feature_map, B, H, W, C, rec, rowstart,
-                         R, crop_h, crop_w, 0.0f, out, Q, ic);
+                         R, crop_h, crop_w, 0.0f, out, Q, ic, rg, gpx);
       return check_launch("roi_pooling (staged rows)");
     }
   }
