@@ -209,7 +209,11 @@ int frcnn_rpn_targets(const float *anchors, const float *gt_boxes, const int32_t
  * lives in a file-scope device array of FRCNN_RPN_TARGETS_STATIC_MAX_BYTES that every GPU the library runs on holds until
  * the process ends; shapes needing more are FRCNN_EUNSUPPORTED.  All calls on one GPU share that array: calls that
  * overlap on one GPU (different streams, different threads) race -- serialise them on one stream.  Same results as
- * frcnn_rpn_targets. */
+ * frcnn_rpn_targets.
+ * Graph capture: the FIRST call on a device resolves the array's address (hipGetSymbolAddress) and may raise the kernels'
+ * dynamic-LDS limit (hipFuncSetAttribute); neither is legal while a stream is capturing.  Make one eager call per device,
+ * with the largest N and M that will be captured, before capturing; later calls issue kernel launches and one
+ * hipMemsetAsync only. */
 #define FRCNN_RPN_TARGETS_STATIC_MAX_BYTES ((size_t)8 << 20) /* covers B=64, N=9216, M=100 (4.8 MB) and B=16, N=35721 */
 int frcnn_rpn_targets_static(const float *anchors, const float *gt_boxes, const int32_t *gt_labels,
                              const int32_t *rnd_pos, const int32_t *rnd_neg, uint64_t seed, int B, int N,
