@@ -15,6 +15,7 @@ for mode in pipeline sequential; do
   timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace_$mode -o t -- \
     python3 $root/bench.py $drv --no-cpu-baseline --no-other-configs --no-other-schedule --mode $mode > $out/${tag}_bench_$mode.json.log 2> $out/${tag}_trace_$mode.err
   cp $(find $out/${tag}_trace_$mode -name '*kernel_stats.csv' | head -1) $out/${tag}_bench_${mode}_kernel_stats.csv
+  python3 $root/tools/block_timeline.py $(find $out/${tag}_trace_$mode -name '*kernel_trace.csv' | head -1) 90 > $out/${tag}_bench_${mode}_timeline.txt
   rm -rf $out/${tag}_trace_$mode
 done
 for c in FETCH_SIZE WRITE_SIZE; do
