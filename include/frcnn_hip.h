@@ -145,6 +145,19 @@ int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, cons
                       int crop_h, int crop_w, float *out, void *workspace, size_t workspace_bytes,
                       frcnn_stream_t stream);
 
+/* frcnn_roi_pooling in two calls, for callers that overlap batches on several streams (models/faster_rcnn.py:264-293, same
+ * results).  The source-row-ownership schedule starts with a pre-pass that needs the RoIs only: frcnn_roi_pooling_prepare
+ * runs it on `stream` -- typically the stream that produced the RoIs -- into `workspace` and sets *prepared = 1; the crop
+ * itself is then frcnn_roi_pooling_prepared with the SAME arguments on any stream ordered after the first call, and
+ * `workspace` must stay untouched in between (one workspace per batch in flight).  *prepared = 0 (nothing was launched)
+ * means these arguments take another schedule: call frcnn_roi_pooling instead. */
+int frcnn_roi_pooling_prepare(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
+                              int crop_h, int crop_w, const float *out, void *workspace, size_t workspace_bytes,
+                              int *prepared, frcnn_stream_t stream);
+int frcnn_roi_pooling_prepared(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
+                               int crop_h, int crop_w, float *out, void *workspace, size_t workspace_bytes,
+                               frcnn_stream_t stream);
+
 /* The same operation (models/faster_rcnn.py:283-288, RoIPooling layout: box_ind == NULL) for `groups` (1..4)
  * independent batches of one shape in ONE launch: images / boxes / outs are HOST arrays of `groups` device pointers
  * ((B,H,W,C), (n,4), (n,ch,cw,C) each).  The reference calls the layer once per batch; a serving loop that has

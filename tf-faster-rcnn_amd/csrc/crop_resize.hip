@@ -583,8 +583,11 @@ struct CropGroups {
   int pf_lead;      // ... dispatched this many boxes before the image's first box
 };
 
+#ifndef FRCNN_CROP_NT
+#define FRCNN_CROP_NT 256  // threads per workgroup of the box kernel (diagnostic builds: 512 / 1024)
+#endif
 template <int VEC, bool ROWS, int WPE, bool PF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+__global__ __launch_bounds__(FRCNN_CROP_NT) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void crop_resize_kernel(
     CropGroups gr, int B, int H, int W, int C,
     const int *__restrict__ box_ind, int units, int boxes_per_image, int ch, int cw, float extrap) {
@@ -617,7 +620,7 @@ void crop_resize_kernel(
       const char *src = reinterpret_cast<const char *>(image) + (long long)img_i * image_bytes;
       f32x4 acc = (f32x4)(0.0f);
 #pragma unroll 8
-      for (long long o = ((long long)piece * 256 + tid) * 16; o + 16 <= image_bytes; o += (long long)gr.pf_blocks * 256 * 16) {
+      for (long long o = ((long long)piece * FRCNN_CROP_NT + tid) * 16; o + 16 <= image_bytes; o += (long long)gr.pf_blocks * FRCNN_CROP_NT * 16) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(src + o);
         acc.x += v.x;  // (any use keeps the load; nothing is stored)
       }
@@ -668,18 +671,18 @@ void crop_resize_kernel(
     char *__restrict__ dstb = reinterpret_cast<char *>(out + ((long long)box * ch * cw + pbeg + p0) * C);
     int p = tid / CV;
     int c = tid - p * CV;
-    const int dp = 256 / CV, dc = 256 - dp * CV;
+    const int dp = FRCNN_CROP_NT / CV, dc = FRCNN_CROP_NT - dp * CV;
 #ifndef FRCNN_CROP_UNROLL
 #define FRCNN_CROP_UNROLL 4
 #endif
     // FRCNN_CROP_UNROLL outputs per lane per trip, all their taps issued before the first lerp.  Unrolled by hand (the
     // packed-subtract asm is convergent, which rules out the compiler's runtime unroll): lanes past the end recompute
     // the last element (in-bounds loads) and skip the store.
-    for (int e0 = tid; e0 < total; e0 += 256 * FRCNN_CROP_UNROLL) {
+    for (int e0 = tid; e0 < total; e0 += FRCNN_CROP_NT * FRCNN_CROP_UNROLL) {
       vec_t v[FRCNN_CROP_UNROLL];
 #pragma unroll
       for (int u = 0; u < FRCNN_CROP_UNROLL; ++u) {
-        const bool in = e0 + u * 256 < total;
+        const bool in = e0 + u * FRCNN_CROP_NT < total;
         const PixParam prm = pp[in ? p : 0];
         v[u] = bilerp<vec_t>(base, prm, (unsigned)(in ? c : 0) * (unsigned)sizeof(vec_t), extrap);
         c += dc;
@@ -691,7 +694,7 @@ void crop_resize_kernel(
       }
 #pragma unroll
       for (int u = 0; u < FRCNN_CROP_UNROLL; ++u) {
-        const int e = e0 + u * 256;
+        const int e = e0 + u * FRCNN_CROP_NT;
         if (e < total) {
           vec_t *d = reinterpret_cast<vec_t *>(dstb + (size_t)((unsigned)e * (unsigned)sizeof(vec_t)));
 #ifdef FRCNN_CROP_PLAIN_STORE
@@ -750,7 +753,7 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   FRCNN_REQUIRE((long long)crop_h * crop_w < (1ll << 24), "crop_and_resize: crop too large");
   if (n == 0) return FRCNN_OK;
   const bool vec4 = (C % 4 == 0) && aligned_to(image, 16) && aligned_to(out, 16);
-  dim3 grid((unsigned)n), block(256);
+  dim3 grid((unsigned)n), block(256), box_block(FRCNN_CROP_NT);
   // The box kernel keeps the one or two images an XCD is working on in its 4 MiB L2.  An image that does not fit there
   // (e.g. 63x63x576 = 9.1 MB) is read through the channel-slice kernel instead, each XCD holding one eighth of it
   // (measured: 179 against 232 us at config 5; 23 % slower than the box kernel at config 2, whose images fit).
@@ -774,18 +777,18 @@ extern "C" int frcnn_crop_and_resize(const float *image, int B, int H, int W, in
   gr.out[0] = out;
   gr.n_per_group = 0;
   if (use_rows) {
-    hipLaunchKernelGGL((crop_resize_kernel<4, true, 6>), dim3((unsigned)(n * crop_h)), block, 0, (hipStream_t)stream, gr,
+    hipLaunchKernelGGL((crop_resize_kernel<4, true, 6>), dim3((unsigned)(n * crop_h)), box_block, 0, (hipStream_t)stream, gr,
                        B, H, W, C, box_ind, n * crop_h, boxes_per_image, crop_h, crop_w, extrapolation_value);
   } else if (vec4) {
     unsigned pf_grid = 0;
     if (!box_ind && (pf_grid = crop_warmup_grid(gr, n, boxes_per_image, B, (long long)H * W * C * 4)) != 0)
-      hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU, true>), dim3(pf_grid), block, 0, (hipStream_t)stream,
+      hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU, true>), dim3(pf_grid), box_block, 0, (hipStream_t)stream,
                          gr, B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
     else
-      hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
+      hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), grid, box_block, 0, (hipStream_t)stream, gr,
                          B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
   } else {
-    hipLaunchKernelGGL((crop_resize_kernel<1, false, FRCNN_CROP_WAVES_PER_EU>), grid, block, 0, (hipStream_t)stream, gr,
+    hipLaunchKernelGGL((crop_resize_kernel<1, false, FRCNN_CROP_WAVES_PER_EU>), grid, box_block, 0, (hipStream_t)stream, gr,
                        B, H, W, C, box_ind, n, boxes_per_image, crop_h, crop_w, extrapolation_value);
   }
   return check_launch("crop_and_resize");
@@ -801,6 +804,126 @@ static size_t stage_rec_offset(int B, int R) { return stage_rank_offset(B, R) + 
 extern "C" size_t frcnn_roi_pooling_workspace_bytes(int B, int R) {
   if (B <= 0 || R <= 0) return 256;
   return stage_rec_offset(B, R) + round_up((size_t)B * R * kStageMaxPixels * sizeof(StageRec), 256) + 256;
+}
+
+// The LDS-staged schedule of frcnn_roi_pooling in three pieces, so that the pre-pass (which needs the RoIs only) can run on
+// another stream than the crop (frcnn_roi_pooling_prepare / frcnn_roi_pooling_prepared).
+struct StagePlan {
+  int Q = 0;  // channel parts; 0: this call does not take the staged schedule
+  int ic = 0, rg = 0, gpx = 0;
+  size_t lds = 0;
+};
+
+static StagePlan stage_plan(const float *feature_map, int B, int H, int W, int C, const float *rois, int R, int crop_h, int crop_w,
+                            const float *out, const void *workspace, size_t workspace_bytes) {
+  StagePlan plan;
+  const long long image_bytes = (long long)H * W * C * 4;
+  const int rb = knob(kKnobCropStage, -1);
+  const bool want = rb >= 0 ? rb != 0 : (image_bytes > 4ll * 1024 * 1024 && !knob_set(kKnobCropSplit) && !knob_set(kKnobCropSlice));
+  const long long nb = (long long)R * crop_h;
+  const int NT = 1024;
+  int ic = 64;  // items per chunk of parameters
+  if (crop_w > 0 && ic * crop_w > NT) ic = NT / crop_w;
+  const int CV = C / 4;
+  const bool fits = B > 0 && R > 0 && H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
+                    aligned_to(out, 16) && aligned_to(rois, 16) && image_bytes < (1ll << 32) && H <= 1023 && W <= 1023 &&
+                    nb <= 65535 && crop_h * crop_w <= kStageMaxPixels && ic > 0 && (long long)B * nb * crop_w < (1ll << 31) &&
+                    (long long)B * R * crop_h * crop_w * CV < (1ll << 31) && workspace && aligned_to(workspace, 256) &&
+                    workspace_bytes >= frcnn_roi_pooling_workspace_bytes(B, R);
+  if (!(want && fits)) return plan;
+  const int q_min = rb > 0 ? knob(kKnobCropSplit, 0) : 0;
+  for (int cand = 1; cand <= 8; cand *= 2) {  // the fewest channel parts with which two rows and the parameters fit the LDS
+    if (CV % cand || cand < q_min) continue;
+    const size_t need = (size_t)2 * W * (CV / cand) * 16 + (size_t)ic * crop_w * sizeof(PixParam);
+    if (need <= 160 * 1024) {
+      plan.Q = cand;
+      plan.lds = need;
+      break;
+    }
+  }
+  if (plan.Q == 0) return plan;
+  plan.ic = ic;
+  // Row pairs per XCD group: the largest of 8 / 4 / 2 that deals the H + 1 pairs to the 8 XCDs within 7 % of evenly, else 0
+  // (pairs dealt round-robin, every row fetched twice).  Config 5 (H = 63), 16 images, cold inputs, FETCH_SIZE x 2 / kernel
+  // time under the profiler / crop time in the stage pipeline: 0: 298 MB, 145.3 us, 156.6 us; 4: 185 MB, 141.4, 154.9;
+  // 8: 166 MB (1.14 x the feature maps), 143.6, 155.4.  FRCNN_CROP_PREFETCH overrides (diagnostic).
+  int rg = 0;
+  for (int cand = 8; cand >= 2 && !rg; cand >>= 1) {
+    const int slots = (((H + 1 + cand - 1) / cand + 7) / 8) * 8 * cand;
+    if ((long long)slots * 100 <= (long long)(H + 1) * 107) rg = cand;
+  }
+  rg = knob(kKnobCropPrefetch, rg);
+  plan.rg = rg < 0 ? 0 : (rg > 64 ? 64 : rg);
+  plan.gpx = plan.rg > 0 ? ((H + 1 + plan.rg - 1) / plan.rg + 7) / 8 : 0;  // groups of one image per XCD
+  const long long wgs = plan.rg > 0 ? (long long)8 * B * plan.gpx * plan.rg * plan.Q : (long long)B * plan.Q * (H + 1);
+  if (wgs >= (1ll << 31)) plan.Q = 0;
+  return plan;
+}
+
+static int stage_prepass(const StagePlan &plan, int B, int H, int W, int C, const float *rois, int R, int crop_h, int crop_w,
+                         void *workspace, hipStream_t stream) {
+  (void)plan;
+  const long long nb = (long long)R * crop_h;
+  int *rowstart = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + stage_rowstart_offset(B, R));
+  StageRec *rec = reinterpret_cast<StageRec *>(reinterpret_cast<char *>(workspace) + stage_rec_offset(B, R));
+  unsigned *rank_top = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + stage_rank_offset(B, R));
+  const size_t lds = (size_t)(1024 + 8 + 16) * 4 + (size_t)((nb + 1) & ~1ll) * 2;
+  auto okern = crop_rows_order_kernel;
+  if (lds > 48 * 1024) {
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(okern), lds, "roi_pooling: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, stream, rois, R, H, crop_h, rowstart, rank_top);
+  int rc = check_launch("roi_pooling (row order)");
+  if (rc) return rc;
+  const long long npix_all = (long long)B * nb * crop_w;
+  hipLaunchKernelGGL(crop_rows_records_kernel, dim3((unsigned)((npix_all + 255) / 256)), dim3(256), 0, stream, rois, B, R, H, W, crop_h,
+                     crop_w, C / 4, rank_top, rec);
+  return check_launch("roi_pooling (records)");
+}
+
+static int stage_main(const StagePlan &plan, const float *feature_map, int B, int H, int W, int C, int R, int crop_h, int crop_w,
+                      float *out, void *workspace, hipStream_t stream) {
+  const int *rowstart = reinterpret_cast<const int *>(reinterpret_cast<char *>(workspace) + stage_rowstart_offset(B, R));
+  const StageRec *rec = reinterpret_cast<const StageRec *>(reinterpret_cast<char *>(workspace) + stage_rec_offset(B, R));
+  auto skern = crop_resize_rowstage_kernel<1024>;
+  if (plan.lds > 48 * 1024) {
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), plan.lds, "roi_pooling: hipFuncSetAttribute");
+    if (rc) return rc;
+  }
+  const long long wgs = plan.rg > 0 ? (long long)8 * B * plan.gpx * plan.rg * plan.Q : (long long)B * plan.Q * (H + 1);
+  hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(1024), plan.lds, stream, feature_map, B, H, W, C, rec, rowstart, R, crop_h, crop_w,
+                     0.0f, out, plan.Q, plan.ic, plan.rg, plan.gpx);
+  return check_launch("roi_pooling (staged rows)");
+}
+
+extern "C" int frcnn_roi_pooling_prepare(const float *feature_map, int B, int H, int W, int C, const float *rois, int R, int crop_h,
+                                         int crop_w, const float *out, void *workspace, size_t workspace_bytes, int *prepared,
+                                         frcnn_stream_t stream) {
+  FRCNN_REQUIRE(feature_map && rois && out && prepared, "roi_pooling_prepare: null pointer");
+  FRCNN_REQUIRE(B >= 0 && R >= 0, "roi_pooling_prepare: negative shape");
+  *prepared = 0;
+  if (B == 0 || R == 0) return FRCNN_OK;
+  FRCNN_REQUIRE((long long)B * R < (1ll << 28), "roi_pooling_prepare: too many RoIs");
+  const StagePlan plan = stage_plan(feature_map, B, H, W, C, rois, R, crop_h, crop_w, out, workspace, workspace_bytes);
+  if (plan.Q == 0) return FRCNN_OK;  // another schedule: nothing to prepare, call frcnn_roi_pooling
+  int rc = stage_prepass(plan, B, H, W, C, rois, R, crop_h, crop_w, workspace, (hipStream_t)stream);
+  if (rc) return rc;
+  *prepared = 1;
+  return FRCNN_OK;
+}
+
+extern "C" int frcnn_roi_pooling_prepared(const float *feature_map, int B, int H, int W, int C, const float *rois, int R, int crop_h,
+                                          int crop_w, float *out, void *workspace, size_t workspace_bytes, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(feature_map && rois && out, "roi_pooling_prepared: null pointer");
+  FRCNN_REQUIRE(B >= 0 && R >= 0, "roi_pooling_prepared: negative shape");
+  if (B == 0 || R == 0) return FRCNN_OK;
+  FRCNN_REQUIRE((long long)B * R < (1ll << 28), "roi_pooling_prepared: too many RoIs");
+  const StagePlan plan = stage_plan(feature_map, B, H, W, C, rois, R, crop_h, crop_w, out, workspace, workspace_bytes);
+  if (plan.Q == 0)
+    return set_error(FRCNN_EINVAL, "roi_pooling_prepared: these arguments do not take the prepared schedule "
+                                   "(frcnn_roi_pooling_prepare must have reported prepared = 1 for the same arguments)");
+  return stage_main(plan, feature_map, B, H, W, C, R, crop_h, crop_w, out, workspace, (hipStream_t)stream);
 }
 
 extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
@@ -826,72 +949,11 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
   // workspace; FRCNN_CROP_STAGE = 0 | 1 forces the choice for any size (1 still needs the workspace and the shape limits;
   // with it FRCNN_CROP_SPLIT = Q sets a minimum number of channel parts: diagnostic).
   {
-    const int rb = knob(kKnobCropStage, -1);
-    const bool want = rb >= 0 ? rb != 0 : (image_bytes > 4ll * 1024 * 1024 && !knob_set(kKnobCropSplit) && !knob_set(kKnobCropSlice));
-    const long long nb = (long long)R * crop_h;
-    const int NT = 1024;
-    int ic = 64;  // items per chunk of parameters
-    if (crop_w > 0 && ic * crop_w > NT) ic = NT / crop_w;
-    const int CV = C / 4;
-    int Q = 0;
-    size_t stage_lds = 0;
-    const bool fits = H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
-                      aligned_to(out, 16) && aligned_to(rois, 16) && image_bytes < (1ll << 32) && H <= 1023 && W <= 1023 &&
-                      nb <= 65535 && crop_h * crop_w <= kStageMaxPixels && ic > 0 && (long long)B * nb * crop_w < (1ll << 31) &&
-                      (long long)B * R * crop_h * crop_w * CV < (1ll << 31) && workspace && aligned_to(workspace, 256) &&
-                      workspace_bytes >= frcnn_roi_pooling_workspace_bytes(B, R);
-    if (want && fits) {
-      const int q_min = rb > 0 ? knob(kKnobCropSplit, 0) : 0;
-      for (int cand = 1; cand <= 8; cand *= 2) {  // the fewest channel parts with which two rows and the parameters fit the LDS
-        if (CV % cand || cand < q_min) continue;
-        const size_t need = (size_t)2 * W * (CV / cand) * 16 + (size_t)ic * crop_w * sizeof(PixParam);
-        if (need <= 160 * 1024) {
-          Q = cand;
-          stage_lds = need;
-          break;
-        }
-      }
-    }
-    if (Q > 0) {
-      int *rowstart = reinterpret_cast<int *>(reinterpret_cast<char *>(workspace) + stage_rowstart_offset(B, R));
-      StageRec *rec = reinterpret_cast<StageRec *>(reinterpret_cast<char *>(workspace) + stage_rec_offset(B, R));
-      const size_t lds = (size_t)(1024 + 8 + 16) * 4 + (size_t)((nb + 1) & ~1ll) * 2;
-      auto okern = crop_rows_order_kernel;
-      if (lds > 48 * 1024) {
-        int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(okern), lds, "roi_pooling: hipFuncSetAttribute");
-        if (rc) return rc;
-      }
-      unsigned *rank_top = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + stage_rank_offset(B, R));
-      hipLaunchKernelGGL(okern, dim3((unsigned)B), dim3(1024), lds, (hipStream_t)stream, rois, R, H, crop_h, rowstart, rank_top);
-      int rc = check_launch("roi_pooling (row order)");
+    const StagePlan plan = stage_plan(feature_map, B, H, W, C, rois, R, crop_h, crop_w, out, workspace, workspace_bytes);
+    if (plan.Q > 0) {
+      int rc = stage_prepass(plan, B, H, W, C, rois, R, crop_h, crop_w, workspace, (hipStream_t)stream);
       if (rc) return rc;
-      const long long npix_all = (long long)B * nb * crop_w;
-      hipLaunchKernelGGL(crop_rows_records_kernel, dim3((unsigned)((npix_all + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rois, B, R,
-                         H, W, crop_h, crop_w, CV, rank_top, rec);
-      rc = check_launch("roi_pooling (records)");
-      if (rc) return rc;
-      auto skern = crop_resize_rowstage_kernel<1024>;
-      if (stage_lds > 48 * 1024) {
-        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), stage_lds, "roi_pooling: hipFuncSetAttribute");
-        if (rc) return rc;
-      }
-      // Row pairs per XCD group: the largest of 8 / 4 / 2 that deals the H + 1 pairs to the 8 XCDs within 7 % of evenly, else 0
-      // (pairs dealt round-robin, every row fetched twice).  Config 5 (H = 63), 16 images, cold inputs, FETCH_SIZE x 2 / kernel
-      // time under the profiler / crop time in the stage pipeline: 0: 298 MB, 145.3 us, 156.6 us; 4: 185 MB, 141.4, 154.9;
-      // 8: 166 MB (1.14 x the feature maps), 143.6, 155.4.  FRCNN_CROP_PREFETCH overrides (diagnostic).
-      int rg = 0;
-      for (int cand = 8; cand >= 2 && !rg; cand >>= 1) {
-        const int slots = (((H + 1 + cand - 1) / cand + 7) / 8) * 8 * cand;
-        if ((long long)slots * 100 <= (long long)(H + 1) * 107) rg = cand;
-      }
-      rg = knob(kKnobCropPrefetch, rg);
-      rg = rg < 0 ? 0 : (rg > 64 ? 64 : rg);
-      const int gpx = rg > 0 ? ((H + 1 + rg - 1) / rg + 7) / 8 : 0;  // groups of one image per XCD
-      const long long wgs = rg > 0 ? (long long)8 * B * gpx * rg * Q : (long long)B * Q * (H + 1);
-      FRCNN_REQUIRE(wgs < (1ll << 31), "roi_pooling: too many workgroups");
-      hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(NT), stage_lds, (hipStream_t)stream, feature_map, B, H, W, C, rec, rowstart,
-                         R, crop_h, crop_w, 0.0f, out, Q, ic, rg, gpx);
-      return check_launch("roi_pooling (staged rows)");
+      return stage_main(plan, feature_map, B, H, W, C, R, crop_h, crop_w, out, workspace, (hipStream_t)stream);
     }
   }
   int S = knob(kKnobCropSplit, -1);
@@ -978,11 +1040,11 @@ extern "C" int frcnn_crop_and_resize_multi(const float *const *images, const flo
   }
   gr.n_per_group = n;
   if (const unsigned pf_grid = crop_warmup_grid(gr, n * groups, boxes_per_image, B, (long long)H * W * C * 4))
-    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU, true>), dim3(pf_grid), dim3(256), 0,
+    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU, true>), dim3(pf_grid), dim3(FRCNN_CROP_NT), 0,
                        (hipStream_t)stream, gr, B, H, W, C, (const int *)nullptr, n * groups, boxes_per_image, crop_h, crop_w,
                        extrapolation_value);
   else
-    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), dim3((unsigned)(n * groups)), dim3(256), 0,
+    hipLaunchKernelGGL((crop_resize_kernel<4, false, FRCNN_CROP_WAVES_PER_EU>), dim3((unsigned)(n * groups)), dim3(FRCNN_CROP_NT), 0,
                        (hipStream_t)stream, gr, B, H, W, C, (const int *)nullptr, n * groups, boxes_per_image, crop_h, crop_w,
                        extrapolation_value);
   return check_launch("crop_and_resize_multi");

@@ -253,6 +253,10 @@ class RoIPathPipeline:
         self._ws_prop = torch.empty(max(1, lib.frcnn_roi_bbox_workspace_bytes(B, N, self._K, R)), dtype=torch.uint8, device=dev)
         self._ws_dec = None if self.train else torch.empty(max(1, lib.frcnn_decoder_workspace_bytes(B, R, L, T)), dtype=torch.uint8, device=dev)
         self._ws_pool = torch.empty(max(1, lib.frcnn_roi_pooling_workspace_bytes(B, R)), dtype=torch.uint8, device=dev)
+        # RoIPooling's pre-pass (source-row order of feature maps beyond L2) runs on the proposal stream, a batch ahead of the
+        # crop that consumes it: one workspace per slot then (allocated when the library first reports that schedule)
+        self._ws_stage: Dict[int, torch.Tensor] = {}
+        self._prepared = ctypes.c_int(0)
         self._ws_prop2 = torch.empty_like(self._ws_prop) if self.train else None  # the second proposal lane's workspace
         self._ws_delta: Dict[Tuple[int, int], torch.Tensor] = {}  # train mode: RoIDelta's workspace per (gt boxes per image, lane)
         torch.cuda.synchronize(dev)
@@ -440,6 +444,25 @@ class RoIPathPipeline:
             _lib.check(lib.frcnn_roi_bbox_multi(tab([s.inputs[0] for s in slots]), tab([s.inputs[1] for s in slots]),
                                                 self.roi_bbox.anchors.data_ptr(), self._var_prop, n, B, N, self._K, R,
                                                 self._thr, own["rois"], ws_prop.data_ptr(), ws_prop.numel(), q_prop))
+        # the crop's pre-pass, where its schedule has one: it needs the RoIs only, so it rides on the proposal stream and
+        # the pooling stream carries the crop kernel alone (a group is either prepared as a whole or not at all)
+        prepared = "crop" not in self._skip and "prop" not in self._skip
+        if prepared:
+            for k, s in zip(ks, slots):
+                ws = self._ws_stage.get(k)
+                _lib.check(lib.frcnn_roi_pooling_prepare(s.pending[0].data_ptr(), B, H, W, C, s.rois.data_ptr(), R, ph, pw,
+                                                         s.pooled.data_ptr(), ws.data_ptr() if ws is not None else self._ws_pool.data_ptr(),
+                                                         self._ws_pool.numel(), ctypes.byref(self._prepared), q_prop))
+                if not self._prepared.value:
+                    prepared = False  # (decided by shape and knobs: the same for every batch of the group)
+                    break
+                if ws is None:
+                    # first time for this slot: the pre-pass just went into the shared workspace, which the next batch would
+                    # overwrite -- give the slot its own and run the (cheap) pre-pass again into it
+                    ws = self._ws_stage[k] = torch.empty_like(self._ws_pool)
+                    _lib.check(lib.frcnn_roi_pooling_prepare(s.pending[0].data_ptr(), B, H, W, C, s.rois.data_ptr(), R, ph, pw,
+                                                             s.pooled.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                             ctypes.byref(self._prepared), q_prop))
         ev_rois = self._ev_rois[ks[0]]
         ev_rois.record(q_prop)
 
@@ -469,7 +492,12 @@ class RoIPathPipeline:
         timing = next((s.pending[2] for s in slots if s.pending[2] is not None), None)
         if timing is not None:
             timing[0].record(q_pool)
-        if "crop" not in self._skip:
+        if prepared:
+            for k, s in zip(ks, slots):
+                ws = self._ws_stage[k]
+                _lib.check(lib.frcnn_roi_pooling_prepared(s.pending[0].data_ptr(), B, H, W, C, s.rois.data_ptr(), R, ph, pw,
+                                                          s.pooled.data_ptr(), ws.data_ptr(), ws.numel(), q_pool))
+        elif "crop" not in self._skip:
             _lib.check(lib.frcnn_crop_and_resize_multi(tab([s.pending[0] for s in slots]), own["rois"], own["pooled"],
                                                        n, B, H, W, C, B * R, R, ph, pw, 0.0, self._ws_pool.data_ptr(),
                                                        self._ws_pool.numel(), q_pool))
