@@ -570,6 +570,50 @@ def test_roi_pooling_channel_slice_kernel(pkg, knobs):
     test_roi_pooling(pkg, 1, 63, 576, 40)
 
 
+def test_roi_pooling_in_two_calls(pkg, knobs):
+    """frcnn_roi_pooling_prepare (pre-pass on one stream) + frcnn_roi_pooling_prepared (crop on another, ordered by an event),
+    through the C ABI: same bits as the oracle on a 63x63x576 map (taken by itself) and on small forced shapes; a shape that
+    takes another schedule reports prepared = 0 and launches nothing; the second call without the schedule is an error."""
+    import ctypes
+    lib = pkg._lib.lib()
+    side = torch.cuda.Stream()
+    for (B, G, C, R, force) in [(2, 63, 576, 40, False), (3, 9, 20, 33, True), (1, 5, 8, 300, True)]:
+        if force:
+            knobs.setenv("FRCNN_CROP_STAGE", 1)
+        else:
+            knobs.delenv("FRCNN_CROP_STAGE")
+        fm = synth.feature_map(1, B, G, C)
+        rng = np.random.default_rng(5 + B)
+        rois = np.sort(rng.random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4)
+        rois[:, -2:] = 0.0
+        rois[0, 0] = [-0.2, 0.3, 1.3, 0.6]
+        d_fm, d_rois = dev(fm), dev(rois)
+        out = torch.full((B, R, 7, 7, C), float("nan"), device="cuda")
+        ws = torch.empty(lib.frcnn_roi_pooling_workspace_bytes(B, R), dtype=torch.uint8, device="cuda")
+        prepared = ctypes.c_int(-1)
+        torch.cuda.synchronize()
+        pkg._lib.check(lib.frcnn_roi_pooling_prepare(d_fm.data_ptr(), B, G, G, C, d_rois.data_ptr(), R, 7, 7, out.data_ptr(),
+                                                     ws.data_ptr(), ws.numel(), ctypes.byref(prepared), side.cuda_stream))
+        assert prepared.value == 1
+        torch.cuda.current_stream().wait_stream(side)
+        pkg._lib.check(lib.frcnn_roi_pooling_prepared(d_fm.data_ptr(), B, G, G, C, d_rois.data_ptr(), R, 7, 7, out.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+        assert_bits(out, oracle.roi_pooling(fm, rois, (7, 7)), f"RoIPooling in two calls B={B} G={G} C={C} R={R}")
+    knobs.delenv("FRCNN_CROP_STAGE")
+    # a feature map that fits an XCD's L2 takes the box kernel: nothing to prepare
+    B, G, C, R = 2, 8, 8, 16
+    d_fm, d_rois = dev(synth.feature_map(0, B, G, C)), dev(np.zeros((B, R, 4), np.float32))
+    out = torch.empty((B, R, 7, 7, C), device="cuda")
+    ws = torch.empty(lib.frcnn_roi_pooling_workspace_bytes(B, R), dtype=torch.uint8, device="cuda")
+    prepared = ctypes.c_int(-1)
+    pkg._lib.check(lib.frcnn_roi_pooling_prepare(d_fm.data_ptr(), B, G, G, C, d_rois.data_ptr(), R, 7, 7, out.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), ctypes.byref(prepared), 0))
+    assert prepared.value == 0
+    rc = lib.frcnn_roi_pooling_prepared(d_fm.data_ptr(), B, G, G, C, d_rois.data_ptr(), R, 7, 7, out.data_ptr(), ws.data_ptr(),
+                                        ws.numel(), 0)
+    assert rc != 0 and b"prepared" in lib.frcnn_last_error()
+
+
 def test_crop_and_resize_generic(pkg):
     rng = np.random.default_rng(13)
     img = rng.normal(size=(3, 6, 9, 5)).astype(np.float32)

@@ -530,8 +530,11 @@ class RoIPathPipeline:
             q_done = q_pool
         else:
             ev_heads = self._ev_heads[ks[0]]
-            ev_heads.record(q_pool)
-            ev_heads.wait(q_dec)
+            if "headsev" in self._skip:  # diagnostic: the Decoder ordered behind the RoIs only (right only for precomputed heads)
+                ev_rois.wait(q_dec)
+            else:
+                ev_heads.record(q_pool)
+                ev_heads.wait(q_dec)
             if "dec" not in self._skip:
                 T = int(self.decoder.max_total_size)
                 _lib.check(lib.frcnn_decoder_multi(own["rois"], tab([o[0] for o in outs]), tab([o[1] for o in outs]),
