@@ -219,7 +219,9 @@ class Workload:
                 self.roi_delta = pkg.faster_rcnn.RoIDelta(hp, name="roi_deltas")
             # (frcnn_roi_pooling's choice: feature maps beyond an XCD's L2, or a launch of at most 1024 boxes)
             staged = cfg["G"] * cfg["G"] * cfg["C"] * 4 > 4 * 1024 * 1024
-            self.dominant = ("crop_rows_order_kernel + crop_rows_records_kernel + crop_resize_rowstage_kernel<1024>" if staged else
+            self.dominant = ("crop_resize_rowstage_kernel<1024> (sequential schedule: the bracket also holds its pre-pass, "
+                             "crop_rows_order_kernel + crop_rows_records_kernel; stage pipeline: the pre-pass runs on the proposal "
+                             "stream and the bracket holds one crop launch per batch of the group)" if staged else
                              "crop_resize_slice_kernel" if B * cfg["R"] <= 1024 else "crop_resize_kernel<4>")
             self.dominant_bytes = crop_bytes_per_image(cfg) * B
             self.bound = "hbm"
@@ -490,7 +492,7 @@ def main() -> int:
         raise SystemExit("--mode pipeline is the RoIBBox | RoIPooling | Decoder / RoIDelta stage pipeline (configs 1, 2, 3, 5)")
     gather = not args.no_host_gather
     depth = args.depth or (8 if args.config == 2 else 4)
-    group = args.crop_group or (2 if args.config == 2 else 1)
+    group = args.crop_group or (2 if args.config in (2, 5) else 1)  # (config 3: one 1.6 GB crop per launch is enough; measured)
 
     def auto_sets(c, b, pipelined):
         if args.input_sets:
@@ -714,7 +716,7 @@ def main() -> int:
                 sh2, _ = make_gather(w, c["B"], 0, 1, True)
                 # (config 1: single images, four to a launch of each stage -- the reference's predictor feeds batches of 4,
                 # faster_rcnn_predictor.py:19 -- and eight in flight)
-                p_depth, p_group = (8, 4) if c_id == 1 else (4, 1)
+                p_depth, p_group = (8, 4) if c_id == 1 else ((4, 2) if c_id == 5 else (4, 1))
                 p2 = pipeline_for(w, sh2, p_depth, p_group)
                 o2 = run_blocks(lambda i, ev, w=w, p2=p2: w.submit(p2, i, ev), k, 5, 3, p_group, p2, sh2, spin_ms=OTHER_SPIN_MS)
                 med2 = float(np.median(o2["times"]))
@@ -735,7 +737,8 @@ def main() -> int:
                              (" (train mode: RoIDelta beside the crop)" if c["kind"] == "train" else ""),
                              value=round(c["B"] * k / med2, 1), ms_per_step=round(med2 / k * 1e3, 4),
                              host_enqueue_ms_per_step=round(o2["host_s"] * 1e3, 4),
-                             dominant_kernel=kernel_report(w.dominant, w.bound, d2, w.dominant_bytes))
+                             dominant_kernel=dict(kernel_report(w.dominant, w.bound, d2, w.dominant_bytes * p_group),
+                                                  batches_per_timed_bracket=p_group))
                 if sh2 is not None:
                     st = sh2.stats()
                     entry["host_gather_publish_ms_per_step"] = round(st["publish_seconds"] / max(st["jobs"], 1) * 1e3, 4)
