@@ -157,6 +157,12 @@ int frcnn_roi_pooling_prepare(const float *feature_map, int B, int H, int W, int
 int frcnn_roi_pooling_prepared(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
                                int crop_h, int crop_w, float *out, void *workspace, size_t workspace_bytes,
                                frcnn_stream_t stream);
+/* `groups` (1..4) prepared batches of one shape in ONE launch of the crop kernel (host arrays of `groups` device pointers;
+ * every batch with the workspace its frcnn_roi_pooling_prepare call filled, each of workspace_bytes).  Same results as
+ * `groups` frcnn_roi_pooling_prepared calls. */
+int frcnn_roi_pooling_prepared_multi(const float *const *feature_maps, const float *const *rois, float *const *outs,
+                                     void *const *workspaces, size_t workspace_bytes, int groups, int B, int H,
+                                     int W, int C, int R, int crop_h, int crop_w, frcnn_stream_t stream);
 
 /* The same operation (models/faster_rcnn.py:283-288, RoIPooling layout: box_ind == NULL) for `groups` (1..4)
  * independent batches of one shape in ONE launch: images / boxes / outs are HOST arrays of `groups` device pointers

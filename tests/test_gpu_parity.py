@@ -599,6 +599,23 @@ def test_roi_pooling_in_two_calls(pkg, knobs):
         pkg._lib.check(lib.frcnn_roi_pooling_prepared(d_fm.data_ptr(), B, G, G, C, d_rois.data_ptr(), R, 7, 7, out.data_ptr(),
                                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
         assert_bits(out, oracle.roi_pooling(fm, rois, (7, 7)), f"RoIPooling in two calls B={B} G={G} C={C} R={R}")
+    # three prepared batches in one launch of the crop kernel
+    B, G, C, R = 2, 11, 24, 50
+    fms = [synth.feature_map(10 + g, B, G, C) for g in range(3)]
+    rs = [np.sort(np.random.default_rng(20 + g).random((B, R, 2, 2)).astype(np.float32), axis=2).reshape(B, R, 4) for g in range(3)]
+    d_fms, d_rs = [dev(f) for f in fms], [dev(r) for r in rs]
+    outs = [torch.full((B, R, 7, 7, C), float("nan"), device="cuda") for _ in range(3)]
+    wss = [torch.empty(lib.frcnn_roi_pooling_workspace_bytes(B, R), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    for g in range(3):
+        pkg._lib.check(lib.frcnn_roi_pooling_prepare(d_fms[g].data_ptr(), B, G, G, C, d_rs[g].data_ptr(), R, 7, 7, outs[g].data_ptr(),
+                                                     wss[g].data_ptr(), wss[g].numel(), ctypes.byref(prepared), side.cuda_stream))
+        assert prepared.value == 1
+    torch.cuda.current_stream().wait_stream(side)
+    tab = pkg._lib.ptr_table
+    pkg._lib.check(lib.frcnn_roi_pooling_prepared_multi(tab(d_fms), tab(d_rs), tab(outs), tab(wss), wss[0].numel(), 3, B, G, G, C, R,
+                                                        7, 7, torch.cuda.current_stream().cuda_stream))
+    for g in range(3):
+        assert_bits(outs[g], oracle.roi_pooling(fms[g], rs[g], (7, 7)), f"RoIPooling, three prepared batches in one launch: batch {g}")
     knobs.delenv("FRCNN_CROP_STAGE")
     # a feature map that fits an XCD's L2 takes the box kernel: nothing to prepare
     B, G, C, R = 2, 8, 8, 16
@@ -1104,6 +1121,16 @@ def test_pipeline_matches_oracle_and_sequential(pkg, depth, heads_callable, crop
         for name, want in (("roi_bboxes", rois), ("roi_pooled", pooled), ("bboxes", boxes), ("labels", labels), ("scores", sc)):
             assert_bits(got[i][name], want, f"pipeline batch {i} {name} vs oracle")
             assert_bits(got[i][name], seq[name].cpu().numpy(), f"pipeline batch {i} {name} vs sequential")
+
+
+@pytest.mark.parametrize("depth,crop_group", [(1, 1), (4, 1), (4, 2), (4, 4), (3, 3)])
+def test_pipeline_with_prepared_roi_pooling(pkg, knobs, depth, crop_group):
+    """The stage pipeline when RoIPooling takes the source-row schedule (forced here on a small feature map; taken by itself
+    beyond 4 MiB per image): the pre-pass rides on the proposal stream into a per-slot workspace, the pooling stream runs ONE
+    grouped crop launch (frcnn_roi_pooling_prepared_multi).  Same bits as the oracle, inference and training order."""
+    knobs.setenv("FRCNN_CROP_STAGE", 1)
+    test_pipeline_matches_oracle_and_sequential(pkg, depth, depth % 2 == 0, crop_group)
+    test_train_pipeline_matches_oracle_and_sequential(pkg, depth, crop_group, 96, depth % 2 == 1)
 
 
 @pytest.mark.parametrize("depth,crop_group,R,with_heads", [(1, 1, 96, False), (3, 1, 600, True), (4, 2, 96, True), (3, 3, 600, False)])

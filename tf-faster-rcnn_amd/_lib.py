@@ -52,6 +52,7 @@ SIGNATURES: Dict[str, Tuple[Any, Sequence[Any]]] = {
     "frcnn_roi_pooling": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "frcnn_roi_pooling_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp]),
     "frcnn_roi_pooling_prepared": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "frcnn_roi_pooling_prepared_multi": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "frcnn_crop_and_resize_multi": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "frcnn_decoder_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "frcnn_decoder": (_i, [_vp, _vp, _vp, _c_float_p, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -423,12 +423,19 @@ __global__ __launch_bounds__(256) void crop_rows_records_kernel(const float *__r
 
 // grid: one workgroup of NT threads per (image b, top row t <= H, channel part q); see the index decode for the order.
 // LDS: 2 * W * CQ float4 of rows | ic * cw PixParam (off_* are float4 indices into the staged rows here).
+// Up to kStageGroups batches of one shape per launch (frcnn_roi_pooling_prepared_multi): image index b of the launch is image
+// b % B of batch b / B; every batch has its own feature maps, output and pre-pass results.
+static const int kStageGroups = 4;
+struct StageGroups {
+  const float *image[kStageGroups];
+  float *out[kStageGroups];
+  const StageRec *rec[kStageGroups];
+  const int *rowstart[kStageGroups];
+};
+
 template <int NT>
-__global__ __launch_bounds__(NT) void crop_resize_rowstage_kernel(const float *__restrict__ image, int B, int H, int W, int C,
-                                                                  const StageRec *__restrict__ rec,
-                                                                  const int *__restrict__ rowstart, int R, int ch, int cw,
-                                                                  float extrap, float *__restrict__ out, int Q, int ic, int rg,
-                                                                  int gpx) {
+__global__ __launch_bounds__(NT) void crop_resize_rowstage_kernel(StageGroups gr, int groups, int B, int H, int W, int C, int R,
+                                                                  int ch, int cw, float extrap, int Q, int ic, int rg, int gpx) {
   extern __shared__ __attribute__((aligned(16))) f32x4 rows[];
   const int tid = threadIdx.x;
   int q, t, b;
@@ -449,7 +456,25 @@ __global__ __launch_bounds__(NT) void crop_resize_rowstage_kernel(const float *_
     t = (blockIdx.x / Q) % (H + 1);
     b = blockIdx.x / (Q * (H + 1));
   }
-  if (b >= B) return;
+  if (b >= B * groups) return;
+  // which batch (workgroup-uniform; selects instead of indexing the kernel-argument arrays dynamically)
+  const float *__restrict__ image = gr.image[0];
+  float *__restrict__ out = gr.out[0];
+  const StageRec *__restrict__ rec = gr.rec[0];
+  const int *__restrict__ rowstart = gr.rowstart[0];
+  if (groups > 1) {
+    const int g = b / B;
+    b -= g * B;
+#pragma unroll
+    for (int i = 1; i < kStageGroups; ++i) {
+      if (g == i) {
+        image = gr.image[i];
+        out = gr.out[i];
+        rec = gr.rec[i];
+        rowstart = gr.rowstart[i];
+      }
+    }
+  }
   const int n = R * ch;
   const int r0 = rowstart[(long long)b * (H + 2) + t], r1 = rowstart[(long long)b * (H + 2) + t + 1];
   if (r0 >= r1) return;  // nobody samples this row pair
@@ -882,18 +907,25 @@ static int stage_prepass(const StagePlan &plan, int B, int H, int W, int C, cons
   return check_launch("roi_pooling (records)");
 }
 
-static int stage_main(const StagePlan &plan, const float *feature_map, int B, int H, int W, int C, int R, int crop_h, int crop_w,
-                      float *out, void *workspace, hipStream_t stream) {
-  const int *rowstart = reinterpret_cast<const int *>(reinterpret_cast<char *>(workspace) + stage_rowstart_offset(B, R));
-  const StageRec *rec = reinterpret_cast<const StageRec *>(reinterpret_cast<char *>(workspace) + stage_rec_offset(B, R));
+static int stage_main(const StagePlan &plan, const float *const *feature_maps, float *const *outs, void *const *workspaces, int groups,
+                      int B, int H, int W, int C, int R, int crop_h, int crop_w, hipStream_t stream) {
+  StageGroups gr = {};
+  for (int g = 0; g < groups; ++g) {
+    gr.image[g] = feature_maps[g];
+    gr.out[g] = outs[g];
+    gr.rowstart[g] = reinterpret_cast<const int *>(reinterpret_cast<char *>(workspaces[g]) + stage_rowstart_offset(B, R));
+    gr.rec[g] = reinterpret_cast<const StageRec *>(reinterpret_cast<char *>(workspaces[g]) + stage_rec_offset(B, R));
+  }
   auto skern = crop_resize_rowstage_kernel<1024>;
   if (plan.lds > 48 * 1024) {
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(skern), plan.lds, "roi_pooling: hipFuncSetAttribute");
     if (rc) return rc;
   }
-  const long long wgs = plan.rg > 0 ? (long long)8 * B * plan.gpx * plan.rg * plan.Q : (long long)B * plan.Q * (H + 1);
-  hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(1024), plan.lds, stream, feature_map, B, H, W, C, rec, rowstart, R, crop_h, crop_w,
-                     0.0f, out, plan.Q, plan.ic, plan.rg, plan.gpx);
+  const long long Bt = (long long)B * groups;
+  const long long wgs = plan.rg > 0 ? 8 * Bt * plan.gpx * plan.rg * plan.Q : Bt * plan.Q * (H + 1);
+  if (wgs >= (1ll << 31)) return set_error(FRCNN_EUNSUPPORTED, "roi_pooling: too many workgroups");
+  hipLaunchKernelGGL(skern, dim3((unsigned)wgs), dim3(1024), plan.lds, stream, gr, groups, B, H, W, C, R, crop_h, crop_w, 0.0f, plan.Q,
+                     plan.ic, plan.rg, plan.gpx);
   return check_launch("roi_pooling (staged rows)");
 }
 
@@ -923,7 +955,28 @@ extern "C" int frcnn_roi_pooling_prepared(const float *feature_map, int B, int H
   if (plan.Q == 0)
     return set_error(FRCNN_EINVAL, "roi_pooling_prepared: these arguments do not take the prepared schedule "
                                    "(frcnn_roi_pooling_prepare must have reported prepared = 1 for the same arguments)");
-  return stage_main(plan, feature_map, B, H, W, C, R, crop_h, crop_w, out, workspace, (hipStream_t)stream);
+  void *const wsp = workspace;
+  return stage_main(plan, &feature_map, &out, &wsp, 1, B, H, W, C, R, crop_h, crop_w, (hipStream_t)stream);
+}
+
+extern "C" int frcnn_roi_pooling_prepared_multi(const float *const *feature_maps, const float *const *rois, float *const *outs,
+                                                void *const *workspaces, size_t workspace_bytes, int groups, int B, int H, int W,
+                                                int C, int R, int crop_h, int crop_w, frcnn_stream_t stream) {
+  FRCNN_REQUIRE(feature_maps && rois && outs && workspaces, "roi_pooling_prepared_multi: null table");
+  FRCNN_REQUIRE(groups >= 1 && groups <= kStageGroups, "roi_pooling_prepared_multi: 1..%d batches per launch (got %d)", kStageGroups, groups);
+  FRCNN_REQUIRE(B >= 0 && R >= 0, "roi_pooling_prepared_multi: negative shape");
+  if (B == 0 || R == 0) return FRCNN_OK;
+  FRCNN_REQUIRE((long long)B * R < (1ll << 28), "roi_pooling_prepared_multi: too many RoIs");
+  StagePlan plan;
+  for (int g = 0; g < groups; ++g) {
+    FRCNN_REQUIRE(feature_maps[g] && rois[g] && outs[g], "roi_pooling_prepared_multi: null pointer in batch %d", g);
+    // (the plan depends on the shape and the schedule knobs; the pointers only have to pass its alignment checks)
+    plan = stage_plan(feature_maps[g], B, H, W, C, rois[g], R, crop_h, crop_w, outs[g], workspaces[g], workspace_bytes);
+    if (plan.Q == 0)
+      return set_error(FRCNN_EINVAL, "roi_pooling_prepared_multi: batch %d does not take the prepared schedule "
+                                     "(frcnn_roi_pooling_prepare must have reported prepared = 1 for the same arguments)", g);
+  }
+  return stage_main(plan, feature_maps, outs, workspaces, groups, B, H, W, C, R, crop_h, crop_w, (hipStream_t)stream);
 }
 
 extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, int C, const float *rois, int R,
@@ -953,7 +1006,8 @@ extern "C" int frcnn_roi_pooling(const float *feature_map, int B, int H, int W, 
     if (plan.Q > 0) {
       int rc = stage_prepass(plan, B, H, W, C, rois, R, crop_h, crop_w, workspace, (hipStream_t)stream);
       if (rc) return rc;
-      return stage_main(plan, feature_map, B, H, W, C, R, crop_h, crop_w, out, workspace, (hipStream_t)stream);
+      void *const wsp = workspace;
+      return stage_main(plan, &feature_map, &out, &wsp, 1, B, H, W, C, R, crop_h, crop_w, (hipStream_t)stream);
     }
   }
   int S = knob(kKnobCropSplit, -1);

@@ -493,10 +493,9 @@ class RoIPathPipeline:
         if timing is not None:
             timing[0].record(q_pool)
         if prepared:
-            for k, s in zip(ks, slots):
-                ws = self._ws_stage[k]
-                _lib.check(lib.frcnn_roi_pooling_prepared(s.pending[0].data_ptr(), B, H, W, C, s.rois.data_ptr(), R, ph, pw,
-                                                          s.pooled.data_ptr(), ws.data_ptr(), ws.numel(), q_pool))
+            _lib.check(lib.frcnn_roi_pooling_prepared_multi(tab([s.pending[0] for s in slots]), own["rois"], own["pooled"],
+                                                            tab([self._ws_stage[k] for k in ks]), self._ws_pool.numel(), n, B, H, W,
+                                                            C, R, ph, pw, q_pool))
         elif "crop" not in self._skip:
             _lib.check(lib.frcnn_crop_and_resize_multi(tab([s.pending[0] for s in slots]), own["rois"], own["pooled"],
                                                        n, B, H, W, C, B * R, R, ph, pw, 0.0, self._ws_pool.data_ptr(),
