@@ -848,6 +848,8 @@ static StagePlan stage_plan(const float *feature_map, int B, int H, int W, int C
   const long long nb = (long long)R * crop_h;
   const int NT = 1024;
   int ic = 64;  // items per chunk of parameters
+  const bool ic_forced = rb > 0 && knob(kKnobCropSort, 0) > 1;
+  if (ic_forced) ic = knob(kKnobCropSort, 0);  // (diagnostic: FRCNN_CROP_STAGE=1 FRCNN_CROP_SORT=items per chunk)
   if (crop_w > 0 && ic * crop_w > NT) ic = NT / crop_w;
   const int CV = C / 4;
   const bool fits = B > 0 && R > 0 && H > 0 && W > 0 && C > 0 && crop_h > 0 && crop_w > 0 && (C % 4 == 0) && aligned_to(feature_map, 16) &&
@@ -867,6 +869,16 @@ static StagePlan stage_plan(const float *feature_map, int B, int H, int W, int C
     }
   }
   if (plan.Q == 0) return plan;
+  if (!ic_forced && ic > 32) {
+    // half the parameter area when that lets one more workgroup share the CU's LDS (one loads its rows while the other
+    // stores): config 2's shape forced through this schedule, Q = 2: 120-121 k images/s against 116.7 k in the stage pipeline
+    const size_t rows_bytes = (size_t)2 * W * (CV / plan.Q) * 16, lds_cu = 160 * 1024;
+    const size_t small = rows_bytes + (size_t)32 * crop_w * sizeof(PixParam);
+    if (lds_cu / small > lds_cu / plan.lds) {
+      ic = 32;
+      plan.lds = small;
+    }
+  }
   plan.ic = ic;
   // Row pairs per XCD group: the largest of 8 / 4 / 2 that deals the H + 1 pairs to the 8 XCDs within 7 % of evenly, else 0
   // (pairs dealt round-robin, every row fetched twice).  Config 5 (H = 63), 16 images, cold inputs, FETCH_SIZE x 2 / kernel
