@@ -71,6 +71,69 @@ void crop_tile_kernel(const char *__restrict__ image, const PixParam *__restrict
   }
 }
 
+// ---- persistent tile kernel: 8 * J workgroups; XCD x (blockIdx % 8) owns a contiguous eighth of the output; its J
+// workgroups walk it together: in round i workgroup j handles the U tiles ((i*U + u)*J + j) of 256 float4 (4 KB), so the
+// XCD's write front is U*J*4 KB wide and moves in address order.  Parameters are prefetched one round ahead.
+template <int CV, int U, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void crop_ptile_kernel(const char *__restrict__ image, const PixParam *__restrict__ params, f32x4 *__restrict__ out,
+                       unsigned n4, float extrap) {
+  const unsigned x = blockIdx.x & 7, j = blockIdx.x >> 3, J = gridDim.x >> 3;
+  const unsigned tiles_all = (n4 + 255u) / 256u;
+  const unsigned q = tiles_all >> 3, r = tiles_all & 7;
+  const unsigned t0 = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;  // first tile of this XCD
+  const unsigned nt = q + (x < r ? 1u : 0u);
+  const unsigned rounds = (nt + U * J - 1) / (U * J);
+  auto elem = [&](unsigned i, int u) -> unsigned {
+    const unsigned t = (i * U + u) * J + j;
+    return t < nt ? (t0 + t) * 256u + threadIdx.x : 0xFFFFFFFFu;
+  };
+  // wave-uniform parameters (scalar loads): a wave's 64 float4 span at most two pixels (CV >= 64)
+  PixParam na[U], nb[U];
+  auto load_params = [&](unsigned i, PixParam *da, PixParam *db) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      unsigned e = elem(i, u);
+      e = e < n4 ? e : 0u;
+      const unsigned gpw = __builtin_amdgcn_readfirstlane(e / CV);
+      da[u] = params[gpw];
+      db[u] = params[gpw + 1];
+    }
+  };
+  load_params(0, na, nb);
+  for (unsigned i = 0; i < rounds; ++i) {
+    PixParam ca[U], cb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ca[u] = na[u];
+      cb[u] = nb[u];
+    }
+    if (i + 1 < rounds) load_params(i + 1, na, nb);
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      unsigned e = elem(i, u);
+      e = e < n4 ? e : 0u;
+      const unsigned gp = e / CV, c = e - gp * CV;
+      const bool second = gp != (unsigned)__builtin_amdgcn_readfirstlane(gp);
+      PixParam prm;
+      prm.off_tl = second ? cb[u].off_tl : ca[u].off_tl;
+      prm.off_tr = second ? cb[u].off_tr : ca[u].off_tr;
+      prm.off_bl = second ? cb[u].off_bl : ca[u].off_bl;
+      prm.off_br = second ? cb[u].off_br : ca[u].off_br;
+      prm.lx = second ? cb[u].lx : ca[u].lx;
+      prm.ly = second ? cb[u].ly : ca[u].ly;
+      prm.valid = second ? cb[u].valid : ca[u].valid;
+      v[u] = bilerp<f32x4>(image, prm, c * 16u, extrap);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned e = elem(i, u);
+      if (e < n4) __builtin_nontemporal_store(v[u], &out[e]);
+    }
+  }
+}
+
 // ---- row kernel: workgroup = (box, output row): cw*CV contiguous float4 (16 KB at 7 x 576) ----------------------------
 template <int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
@@ -423,11 +486,21 @@ int main(int argc, char **argv) {
   ms = time_ms(prepass, iters);
   printf("params pre-pass                    %8.2f us\n", ms * 1e3);
 
+#define PT(U, WPE, J) { \
+    ms = time_ms([&] { prepass(); hipLaunchKernelGGL((crop_ptile_kernel<144, U, WPE>), dim3(8 * J), dim3(256), 0, 0, (const char *)img, params, (f32x4 *)out, n4, 0.f); }, iters); \
+    printf("persistent tiles U=%d wpe=%d J=%d (pre-pass included)   %8.2f us  %7.1f GB/s\n", U, WPE, J, ms * 1e3, alg / ms / 1e6); \
+    check("persistent tiles"); }
+  PT(4, 4, 128) PT(2, 4, 128) PT(4, 4, 64) PT(2, 8, 256) PT(4, 6, 192) PT(1, 8, 256) PT(4, 8, 256) PT(2, 6, 192)
+#define TILE(U, MAP, WPE) { \
+    ms = time_ms([&] { prepass(); hipLaunchKernelGGL((crop_tile_kernel<144, U, MAP, WPE>), dim3((n4 + 256 * U - 1) / (256 * U)), dim3(256), 0, 0, (const char *)img, params, (f32x4 *)out, n4, (n4 + 256 * U - 1) / (256 * U), 0.f); }, iters); \
+    printf("one tile per workgroup U=%d map=%d wpe=%d (pre-pass included) %8.2f us  %7.1f GB/s\n", U, MAP, WPE, ms * 1e3, alg / ms / 1e6); \
+    check("tile"); }
+  TILE(4, 1, 4) TILE(1, 0, 8) TILE(4, 1, 6) TILE(4, 1, 8) TILE(2, 1, 8) TILE(4, 0, 8)
 #define XDD(NT, XB) { \
     ms = time_ms([&] { hipLaunchKernelGGL((crop_xdedupe_kernel<7, XB>), dim3(n), dim3(NT), 0, 0, img, B, H, W, C, boxes, n, R, 7, 0.f, out); }, iters); \
     printf("x-dedupe kernel NT=%d XB=%d             %8.2f us  %7.1f GB/s\n", NT, XB, ms * 1e3, alg / ms / 1e6); \
     check("x-dedupe"); }
-  XDD(192, 4) XDD(128, 4) XDD(192, 2) XDD(128, 2) XDD(192, 3) XDD(64, 2)
+  XDD(192, 4)
 #define ROW(WPE) { \
     ms = time_ms([&] { hipLaunchKernelGGL((crop_row_kernel<WPE>), dim3(n * 7), dim3(256), 0, 0, img, B, H, W, C, boxes, n, R, 7, 7, 0.f, out); }, iters); \
     printf("row kernel wpe=%d                   %8.2f us  %7.1f GB/s\n", WPE, ms * 1e3, alg / ms / 1e6); \
