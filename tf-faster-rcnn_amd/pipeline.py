@@ -113,6 +113,37 @@ class _TrainInputs:
         self.gt_boxes, self.gt_labels, self.rnd_pos, self.rnd_neg, self.seed, self.heads = gt_boxes, gt_labels, rnd_pos, rnd_neg, seed, heads
 
 
+class _Done:
+    """Completion of a slot's batch for the host: one event, or two recorded on different streams (train mode: the crop on the
+    pooling stream, RoIDelta on its proposal lane -- joining them on a stream would put a wait packet between two crops)."""
+
+    __slots__ = ("a", "b", "two")
+
+    def __init__(self) -> None:
+        self.a = _lib.HipEvent(_lib.hipEventDisableTiming)  # host-visible: keeps the system-scope release
+        self.b: Optional[_lib.HipEvent] = None
+        self.two = False
+
+    def record(self, stream: int, second: bool = False) -> None:
+        if second:
+            if self.b is None:
+                self.b = _lib.HipEvent(_lib.hipEventDisableTiming)
+            self.b.record(stream)
+            self.two = True
+        else:
+            self.a.record(stream)
+
+    def synchronize(self) -> None:
+        self.a.synchronize()
+        if self.two:
+            self.b.synchronize()
+
+    def wait(self, stream: int) -> None:
+        self.a.wait(stream)
+        if self.two:
+            self.b.wait(stream)
+
+
 class _Slot:
     __slots__ = ("rois", "pooled", "boxes", "labels", "scores", "done", "inputs", "busy", "pending", "wait_in", "small", "h_small", "host",
                  "failed", "ticket", "rd_deltas", "rd_labels", "tag")
@@ -120,7 +151,7 @@ class _Slot:
     def __init__(self) -> None:
         self.rois = self.pooled = self.boxes = self.labels = self.scores = None
         self.rd_deltas = self.rd_labels = None  # train mode: RoIDelta's (B,R*L,4) deltas and (B,R,L) one-hot labels
-        self.done = _lib.HipEvent(_lib.hipEventDisableTiming)  # host-visible: keeps the system-scope release
+        self.done = _Done()
         self.inputs: Any = None
         self.busy = False
         self.pending: Any = None  # (fm, heads, timing) while the batch waits for its group's crop launch
@@ -189,6 +220,7 @@ class RoIPathPipeline:
         self._lanes = 1 if os.environ.get("FRCNN_PIPE_LANES") == "1" else 2  # (diagnostic: one proposal lane)
         # diagnostic ablation only (results are then wrong): FRCNN_PIPE_SKIP=prop,crop,dec leaves those launches out
         self._skip = set(filter(None, os.environ.get("FRCNN_PIPE_SKIP", "").split(",")))
+        self._idle = True  # no batch of this pipeline on the GPU: set by synchronize(), cleared by the next enqueue
         self.wait_seconds = 0.0  # host time spent blocked on back-pressure (diagnostic)
         self._shape_key: Optional[Tuple[int, ...]] = None
         self._ws_prop: Optional[torch.Tensor] = None
@@ -399,6 +431,7 @@ class RoIPathPipeline:
                 for s in slots:
                     s.failed = exc
                     s.pending = None
+                    s.done.two = False  # (everything was joined on one stream above)
                     s.done.record(q_dec)
             raise
 
@@ -440,10 +473,21 @@ class RoIPathPipeline:
         for k in ks:
             if self.slots[k].wait_in:
                 self._ev_in[k].wait(q_prop)
-        if "prop" not in self._skip:
+        if "prop" in self._skip:
+            pass
+        elif self.train and self._idle:
+            # nothing of this pipeline is running on the GPU (first group after construction / synchronize()): the proposals
+            # have the chip to themselves and take the single-batch entry point, whose one-workgroup-per-image kernels
+            # use 1024 threads (the grouped one picks the 256-thread forms that fit beside a running crop, slower alone)
+            for s in slots:
+                _lib.check(lib.frcnn_roi_bbox(s.inputs[0].data_ptr(), s.inputs[1].data_ptr(), self.roi_bbox.anchors.data_ptr(),
+                                              self._var_prop, B, N, self._K, R, self._thr, s.rois.data_ptr(), None, None,
+                                              ws_prop.data_ptr(), ws_prop.numel(), q_prop))
+        else:
             _lib.check(lib.frcnn_roi_bbox_multi(tab([s.inputs[0] for s in slots]), tab([s.inputs[1] for s in slots]),
                                                 self.roi_bbox.anchors.data_ptr(), self._var_prop, n, B, N, self._K, R,
                                                 self._thr, own["rois"], ws_prop.data_ptr(), ws_prop.numel(), q_prop))
+        self._idle = False
         # the crop's pre-pass, where its schedule has one: it needs the RoIs only, so it rides on the proposal stream and
         # the pooling stream carries the crop kernel alone (a group is either prepared as a whole or not at all)
         prepared = "crop" not in self._skip and "prop" not in self._skip
@@ -485,8 +529,8 @@ class RoIPathPipeline:
                                                    _lib.ptr(ti.rnd_pos), _lib.ptr(ti.rnd_neg), ti.seed, B, R, M, L, self._tot[0],
                                                    self._tot[1], self._var_dec, s.rd_deltas.data_ptr(), s.rd_labels.data_ptr(),
                                                    ws.data_ptr(), ws.numel(), q_prop))
-            ev_delta = self._ev_heads[ks[0]]
-            ev_delta.record(q_prop)
+            for s in slots:  # the batch's RoIDelta half of `done`, on its lane
+                s.done.record(q_prop, second=True)
 
         ev_rois.wait(q_pool)  # (ev_in is implied: the proposal stage waited for it)
         timing = next((s.pending[2] for s in slots if s.pending[2] is not None), None)
@@ -523,9 +567,7 @@ class RoIPathPipeline:
                 outs.append(heads)  # normalised and checked in submit()
 
         if self.train:
-            # the batch is done when its crop (+ heads) AND its RoIDelta are: joined on the pooling stream, where the lane's
-            # RoIDelta has long finished by the time the crop ends
-            ev_delta.wait(q_pool)
+            # the batch is done when its crop (+ heads) AND its RoIDelta are: two events, one per stream (_Done)
             q_done = q_pool
         else:
             ev_heads = self._ev_heads[ks[0]]
@@ -592,6 +634,7 @@ class RoIPathPipeline:
                 s.done.synchronize()
                 s.busy = False
                 s.inputs = None
+        self._idle = True
 
 
 def run_sequential(roi_bbox: RoIBBox, roi_pooling: RoIPooling, decoder: Decoder,
