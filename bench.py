@@ -206,6 +206,7 @@ class Workload:
                 self.sets.append(tuple(torch.roll(t, s % max(B, 1), 0).contiguous() if B > 1 else t.clone() for t in self.sets[0]))
         self.lanes = [torch.cuda.Stream(device) for _ in range(2)] if kind == "targets" else None
         self.last_stream = None  # the stream the last step's outputs were produced on (targets: the step's lane)
+        self.target_out = None   # targets: one recycled (deltas, labels) pair per lane
         if kind == "targets":
             self.dominant = "iou_reduce_kernel + rpn_targets_kernel"
             self.dominant_bytes = targets_bytes_per_image(cfg) * B + N * 16
@@ -270,15 +271,23 @@ class Workload:
         if kind == "targets":
             # consecutive batches go to two alternating HIP streams (the feeders' prefetch lanes, utils/train_utils.py): the
             # chip-wide IoU reductions of batch i + 1 run beside the one-workgroup-per-image target kernel of batch i
+            # (stream= and out= are the wrapper's extra arguments for feeder loops: no stream switch, no allocation; each
+            # lane recycles its own pair of output tensors, stream order keeps step i + 2 behind step i's gather)
             gt, lab = s
-            lane = self.lanes[i % len(self.lanes)] if self.lanes else None
+            li = i % len(self.lanes) if self.lanes else 0
+            lane = self.lanes[li] if self.lanes else None
             q = lane.cuda_stream if lane is not None else cur
-            with (self.torch.cuda.stream(lane) if lane is not None else _NULL_CTX):
-                if ev:
-                    ev[0].record(q)
-                deltas, labels = pkg.train_utils.calculate_rpn_actual_outputs(self.anchors, gt, lab, self.hyper, seed=self.seed + i)
-                if ev:
-                    ev[1].record(q)
+            if self.target_out is None:
+                N = self.anchors.shape[0]
+                self.target_out = [(self.torch.empty((self.B, N, 4), device=self.device), self.torch.empty((self.B, N), device=self.device))
+                                   for _ in range(max(1, len(self.lanes or [])))]
+                self.torch.cuda.synchronize(self.device)
+            if ev:
+                ev[0].record(q)
+            deltas, labels = pkg.train_utils.calculate_rpn_actual_outputs(self.anchors, gt, lab, self.hyper, seed=self.seed + i,
+                                                                          out=self.target_out[li], stream=q)
+            if ev:
+                ev[1].record(q)
             self.last_stream = q
             return {"bbox_labels": labels.view(self.B, -1)}
         rois = self.roi_bbox([s[0], s[1]])

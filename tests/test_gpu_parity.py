@@ -765,6 +765,19 @@ def test_rpn_targets(pkg, B, G, M):
     want_d, want_l = oracle.calculate_rpn_actual_outputs(anchors, gt, labels, hp, (rp, rn))
     assert_bits(got_l, want_l, "rpn labels")
     assert_bits(got_d, want_d, "rpn deltas")
+    # the wrapper's extra arguments for feeder loops: caller-provided outputs and an explicit stream
+    side = torch.cuda.Stream()
+    out = (torch.full((B, N, 4), float("nan"), device="cuda"), torch.full((B, N), float("nan"), device="cuda"))
+    d_in = (dev(anchors), dev(gt), dev(labels), dev(rp), dev(rn))
+    torch.cuda.synchronize()
+    d3, l3 = pkg.train_utils.calculate_rpn_actual_outputs(d_in[0], d_in[1], d_in[2], hp, random_masks=(d_in[3], d_in[4]), out=out,
+                                                          stream=side)
+    side.synchronize()
+    assert d3 is out[0] and l3.data_ptr() == out[1].data_ptr()
+    assert_bits(l3, want_l, "rpn labels (out=, stream=)")
+    assert_bits(d3, want_d, "rpn deltas (out=, stream=)")
+    with pytest.raises(ValueError):
+        pkg.train_utils.calculate_rpn_actual_outputs(d_in[0], d_in[1], d_in[2], hp, out=(out[0], out[1][:, :-1]))
     # in-kernel draw: structural properties
     d2, l2 = pkg.train_utils.calculate_rpn_actual_outputs(dev(anchors), dev(gt), dev(labels), hp, seed=5)
     l2 = l2.cpu().numpy().reshape(B, -1)

@@ -193,9 +193,11 @@ def float4(values: Sequence[float]):
 _workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
 
 
-def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
-    """Scratch buffer cached per (device, stream); stream-ordered reuse is race free."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device))
+def workspace(nbytes: int, device: torch.device, stream: Optional[int] = None) -> torch.Tensor:
+    """Scratch buffer cached per (device, stream); stream-ordered reuse is race free.  ``stream``: the raw handle of the
+    stream the buffer will be used on (default: the current stream)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           stream_ptr(device) if stream is None else stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

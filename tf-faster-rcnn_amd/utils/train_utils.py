@@ -105,7 +105,9 @@ def randomly_select_xyz_mask(mask: torch.Tensor, select_xyz: Any,
 def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, gt_labels: torch.Tensor,
                                  hyper_params: HyperParams,
                                  random_masks: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                                 seed: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                                 seed: Optional[int] = None,
+                                 out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                                 stream: Optional[Any] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """RPN regression and classification targets for a batch.  Mirrors reference
     ``utils/train_utils.py:149-202``: anchors x gt IoU, row/column argmax, positives (IoU > 0.7 or best
     anchor of a valid gt) sampled to ``total_pos_bboxes``, negatives (IoU < 0.3) sampled to fill
@@ -120,6 +122,10 @@ def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, 
         random_masks: optional ``(pos, neg)`` int32 tensors ``(batch, total_anchors)``: the random
             integers of the two sampling calls (extra argument, for reproducibility/parity).
         seed: seed of the in-kernel draw used when ``random_masks`` is omitted.
+        out: optional preallocated ``(bbox_deltas (batch, total_anchors, 4), bbox_labels (batch, total_anchors))`` fp32
+            device tensors to write into (extra argument: a feeder loop that recycles its buffers allocates nothing).
+        stream: optional ``torch.cuda.Stream`` (or raw HIP stream handle) to enqueue on instead of the current stream
+            (extra argument; inputs, outputs and the workspace must be safe to use on it).
 
     Returns:
         ``bbox_deltas (batch, total_anchors, 4)`` and
@@ -153,15 +159,22 @@ def calculate_rpn_actual_outputs(anchors: torch.Tensor, gt_boxes: torch.Tensor, 
     if seed is None:
         # a fresh draw per call, like the reference's unseeded tf.random.uniform (host RNG, no device sync)
         seed = 0 if random_masks is not None else int(torch.randint(0, 2 ** 62, (1,)).item())
-    deltas = torch.empty((B, N, 4), dtype=torch.float32, device=device)
-    labels = torch.empty((B, N), dtype=torch.float32, device=device)
+    if out is None:
+        deltas = torch.empty((B, N, 4), dtype=torch.float32, device=device)
+        labels = torch.empty((B, N), dtype=torch.float32, device=device)
+    else:
+        deltas, labels = out
+        for t, shape in ((deltas, (B, N, 4)), (labels, (B, N))):
+            if tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != device or not t.is_contiguous():
+                raise ValueError(f"out must be contiguous fp32 tensors of shape ({B}, {N}, 4) and ({B}, {N}) on {device}")
+    q = _lib.stream_ptr(device) if stream is None else int(getattr(stream, "cuda_stream", stream))
     L = _lib.lib()
     nbytes = L.frcnn_rpn_targets_workspace_bytes(B, N, M)
-    ws = _lib.workspace(nbytes, device)
+    ws = _lib.workspace(nbytes, device, q)
     with _lib.on_device(device):
         _lib.check(L.frcnn_rpn_targets(_lib.ptr(anchors_t), _lib.ptr(gt_t), _lib.ptr(lab_t), _lib.ptr(rp), _lib.ptr(rn),
                                        int(seed) & 0xFFFFFFFFFFFFFFFF, B, N, M, total_pos, total_neg, variances,
-                                       _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(device)))
+                                       _lib.ptr(deltas), _lib.ptr(labels), _lib.ptr(ws), ws.numel(), q))
     return deltas, labels.reshape(B, feature_map_shape, feature_map_shape, anchor_count)
 
 
